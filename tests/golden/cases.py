@@ -1,0 +1,196 @@
+"""Case definitions shared by ``make_golden.py`` (runs the REAL reference, build container
+only) and by the parity tests (oracle here, HIP path on the GPU box).
+
+Only inputs are defined here, all from the portable generator
+(``dynamics_aware_diffusion_amd/utils/synth.py``) — nothing in this file imports the
+reference, so it travels to the GPU box.  Expected outputs live in the ``*.npz`` files next
+to it.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict
+
+import numpy as np
+
+from dynamics_aware_diffusion_amd.utils import synth
+
+H = 32
+
+SCHEDULE_CASES = [("cosine", 100), ("cosine", 500), ("cosine", 1000), ("linear", 100)]
+SINUSOID_DIMS = [32, 128, 256]
+SINUSOID_T = [0, 1, 50, 999]
+
+# (name, kind, c_in, c_out, L, B)
+UNIT_CASES = [
+    ("cb_16_32_L8", "conv_block", 16, 32, 8, 3),
+    ("cb_32_32_L32", "conv_block", 32, 32, 32, 2),
+    ("rtb_16_32_L8", "res_block", 16, 32, 8, 3),
+    ("rtb_32_32_L4", "res_block", 32, 32, 4, 5),
+    ("rtb_6_32_L32", "res_block", 6, 32, 32, 2),
+    ("down_32_L32", "down", 32, 32, 32, 2),
+    ("down_16_L8", "down", 16, 16, 8, 3),
+    ("up_32_L4", "up", 32, 32, 4, 3),
+    ("up_16_L8", "up", 16, 16, 8, 2),
+]
+UNIT_TIME_DIM = 32
+
+
+def unit_weights(name: str, kind: str, ci: int, co: int, seed: int = 11) -> "OrderedDict[str, np.ndarray]":
+    """Weights of one isolated layer, keyed like the corresponding reference sub-module."""
+    w: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def conv(base: str, a: int, b: int, k: int) -> None:
+        bound = 1.0 / np.sqrt(a * k)
+        w[base + ".weight"] = synth.uniform(seed, name + base + ".w", (b, a, k), bound)
+        w[base + ".bias"] = synth.uniform(seed, name + base + ".b", (b,), bound)
+
+    def norm(base: str, c: int) -> None:
+        w[base + ".weight"] = 1.0 + synth.uniform(seed, name + base + ".g", (c,), 0.3)
+        w[base + ".bias"] = synth.uniform(seed, name + base + ".be", (c,), 0.3)
+
+    if kind == "conv_block":
+        conv("block.0", ci, co, 5)
+        norm("block.1", co)
+    elif kind == "res_block":
+        conv("blocks.0.block.0", ci, co, 5)
+        norm("blocks.0.block.1", co)
+        conv("blocks.1.block.0", co, co, 5)
+        norm("blocks.1.block.1", co)
+        bound = 1.0 / np.sqrt(UNIT_TIME_DIM)
+        w["time_mlp.1.weight"] = synth.uniform(seed, name + "tw", (co, UNIT_TIME_DIM), bound)
+        w["time_mlp.1.bias"] = synth.uniform(seed, name + "tb", (co,), bound)
+        if ci != co:
+            conv("residual_conv", ci, co, 1)
+    elif kind == "down":
+        conv("conv", ci, co, 3)
+    elif kind == "up":
+        bound = 1.0 / np.sqrt(co * 4)
+        w["conv.weight"] = synth.uniform(seed, name + "conv.w", (ci, co, 4), bound)
+        w["conv.bias"] = synth.uniform(seed, name + "conv.b", (co,), bound)
+    else:
+        raise ValueError(kind)
+    return w
+
+
+def unit_inputs(name: str, ci: int, L: int, B: int, seed: int = 12):
+    x = synth.normal_like(seed, name + ".x", (B, ci, L))
+    temb = synth.normal_like(seed, name + ".temb", (B, UNIT_TIME_DIM))
+    return x, temb
+
+
+# ---------------------------------------------------------------------------- full nets
+# name: (obs_dim, act_dim, dim, mults, T_train, weight_seed, affine_jitter)
+NETS = {
+    "tiny": (4, 2, 32, (1, 2, 4), 20, 3, 0.25),
+    "tiny4": (5, 3, 32, (1, 2, 2, 4), 20, 4, 0.25),      # 4 levels, L down to 4, td=8
+    "pointmaze": (4, 2, 128, (1, 2, 4), 100, 0, 0.0),
+    "halfcheetah": (17, 6, 256, (1, 4, 8), 1000, 0, 0.0),
+    "door": (39, 28, 256, (1, 2, 4, 8), 1000, 0, 0.0),
+}
+
+# (case, net, B, t)  — single U-Net forward
+FORWARD_CASES = [
+    ("fwd_tiny", "tiny", 3, 7),
+    ("fwd_tiny4", "tiny4", 5, 13),
+    ("fwd_pointmaze", "pointmaze", 2, 63),
+    ("fwd_halfcheetah", "halfcheetah", 2, 500),
+    ("fwd_door", "door", 2, 999),
+]
+
+# (case, net, T_train, n_sample_steps, B, conditioned, schedule)
+LOOP_CASES = [
+    ("loop_tiny_T20_B1", "tiny", 20, 20, 1, False, "cosine"),
+    ("loop_tiny_T20_B4_cond", "tiny", 20, 20, 4, True, "cosine"),
+    ("loop_tiny_T100_B4_cond", "tiny", 100, 100, 4, True, "cosine"),
+    ("loop_tiny_T100_trunc50_B4", "tiny", 100, 50, 4, False, "cosine"),
+    ("loop_tiny_linear_T20_B4", "tiny", 20, 20, 4, True, "linear"),
+    ("loop_tiny4_T20_B3_cond", "tiny4", 20, 20, 3, True, "cosine"),
+    ("loop_pointmaze_T100_B4_cond", "pointmaze", 100, 100, 4, True, "cosine"),
+]
+
+# (case, net, T, B, guide_weight)
+GUIDE_CASES = [
+    ("guide_tiny_w0p1", "tiny", 20, 3, 0.1),
+    ("guide_tiny_w1", "tiny", 20, 3, 1.0),
+]
+VALUE_HIDDEN = 16
+
+
+def net_dims(net: str):
+    od, ad, dim, mults, T, seed, jitter = NETS[net]
+    return od, ad, od + ad, dim, mults
+
+
+def net_weights(net: str) -> "OrderedDict[str, np.ndarray]":
+    od, ad, dim, mults, T, seed, jitter = NETS[net]
+    return synth.synth_unet_state(od + ad, dim, mults, seed=seed, affine_jitter=jitter)
+
+
+def forward_input(case: str, net: str, B: int) -> np.ndarray:
+    _, _, td, _, _ = net_dims(net)
+    return synth.normal_like(21, case + ".x", (B, H, td))
+
+
+def loop_noise(case: str, net: str, n_steps: int, B: int) -> np.ndarray:
+    """Noise stack [x_T, z_{T-1}, ..., z_0] in the reference's randn call order."""
+    _, _, td, _, _ = net_dims(net)
+    return synth.normal_like(22, case + ".noise", (n_steps + 1, B, H, td))
+
+
+def loop_condition(case: str, net: str) -> np.ndarray:
+    """(1, td) condition as get_action builds it: normalised obs, action part zero
+    (guides/policies.py:210-214)."""
+    od, ad, td, _, _ = net_dims(net)
+    c = np.zeros((1, td), np.float32)
+    c[0, :od] = synth.uniform(23, case + ".cond", (od,), 0.9)
+    return c
+
+
+def value_net_weights(od: int, seed: int = 31) -> Dict[str, np.ndarray]:
+    """Tiny fixed value MLP: V(obs) = W2 tanh(W1 obs + b1) + b2, per horizon step."""
+    return {
+        "w1": synth.uniform(seed, "value.w1", (VALUE_HIDDEN, od), 0.7),
+        "b1": synth.uniform(seed, "value.b1", (VALUE_HIDDEN,), 0.2),
+        "w2": synth.uniform(seed, "value.w2", (1, VALUE_HIDDEN), 0.7),
+        "b2": synth.uniform(seed, "value.b2", (1,), 0.2),
+    }
+
+
+# ---------------------------------------------------------------------------- projection
+# (case, dt, horizon)
+PROJ_MATRIX_CASES = [("P_dt0p1_H8", 0.1, 8), ("P_dt0p01_H8", 0.01, 8), ("P_dt0p1_H32", 0.1, 32)]
+PROJ_SCHEDULES = ["constant", "linear", "quadratic", "noise_schedule"]
+PROJ_T = [0, 10, 99]
+PROJ_STRENGTH = 0.8
+PROJ_B = 5
+
+
+class NormalizerStub:
+    """The 6-attribute duck type the planner consumes (guides/policies.py:159,190,209,
+    334-337); the reference's real normalizer package is absent from the snapshot."""
+
+    def __init__(self, od: int, ad: int, seed: int = 41):
+        self.obs_mean = synth.normal_like(seed, "norm.obs_mean", (od,))
+        self.obs_std = (1.0 + synth.uniform(seed, "norm.obs_std", (od,), 0.5)).astype(np.float32)
+        self.action_mean = synth.normal_like(seed, "norm.act_mean", (ad,))
+        self.action_std = (1.0 + synth.uniform(seed, "norm.act_std", (ad,), 0.5)).astype(np.float32)
+
+    def normalize_observations(self, obs):
+        return ((np.asarray(obs, np.float32) - self.obs_mean) / self.obs_std).astype(np.float32)
+
+    def unnormalize_actions(self, a):
+        return (np.asarray(a, np.float32) * self.action_std + self.action_mean).astype(np.float32)
+
+
+def projection_input(case: str) -> np.ndarray:
+    return synth.normal_like(42, case + ".x", (PROJ_B, H, 6))
+
+
+# --------------------------------------------------------------------------- planner glue
+ACTION_HORIZONS = [1, 8, 32]
+N_GET_ACTION_CALLS = 12
+
+
+def glue_observations() -> np.ndarray:
+    return synth.normal_like(51, "glue.obs", (N_GET_ACTION_CALLS, 4))

@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by running the REAL reference.
+
+Build-container only: it imports the reference's hot-path modules from /root/reference
+through empty stub packages (the shipped package __init__ files import modules that are
+absent from the snapshot — SURVEY.md F3/§8(c)).  Nothing of the reference is copied;
+only inputs (regenerable from ``cases.py``) go in and output arrays come out.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only PREFIX]
+
+Made with torch 2.10.0+rocm7.0 (CPU), numpy 2.2; reference snapshot 2025-10-24.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+for _name, _path in [("m_diffuser", f"{REF}/m_diffuser"),
+                     ("m_diffuser.dynamics", f"{REF}/m_diffuser/dynamics")]:
+    _pkg = types.ModuleType(_name)
+    _pkg.__path__ = [_path]
+    sys.modules[_name] = _pkg
+
+from m_diffuser.models import temporal_unet as ref_unet            # noqa: E402
+from m_diffuser.models.diffusion import GaussianDiffusion           # noqa: E402
+from m_diffuser.guides import policies as ref_pol                   # noqa: E402
+from m_diffuser.dynamics.projection import ProjectionMatrixBuilder  # noqa: E402
+
+from tests.golden import cases                                      # noqa: E402
+
+torch.set_grad_enabled(True)
+
+
+def save(name: str, **arrays) -> None:
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def load_into(module: torch.nn.Module, weights, prefix: str = "") -> None:
+    sd = module.state_dict()
+    for k, v in weights.items():
+        key = prefix + k
+        assert key in sd, key
+        assert tuple(sd[key].shape) == tuple(v.shape), (key, sd[key].shape, v.shape)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(v))
+    missing = [k for k in sd if k.startswith(prefix) and k[len(prefix):] not in weights
+               and not isinstance(module, GaussianDiffusion)]
+    assert not missing, missing
+    module.load_state_dict(sd)
+
+
+@contextlib.contextmanager
+def injected_noise(stack: np.ndarray):
+    """Serve ``stack[0], stack[1], ...`` to successive torch.randn / randn_like calls."""
+    it = iter(torch.from_numpy(np.ascontiguousarray(stack)))
+    real_randn, real_like = torch.randn, torch.randn_like
+
+    def fake_randn(*shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        z = next(it)
+        assert tuple(z.shape) == tuple(shape), (z.shape, shape)
+        return z.clone()
+
+    def fake_like(x, **kw):
+        z = next(it)
+        assert z.shape == x.shape
+        return z.clone()
+
+    torch.randn, torch.randn_like = fake_randn, fake_like
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+
+
+def build_reference(net: str, T: int, schedule: str = "cosine"):
+    od, ad, td, dim, mults = cases.net_dims(net)
+    unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults))
+    load_into(unet, cases.net_weights(net))
+    diff = GaussianDiffusion(unet, cases.H, od, ad, n_timesteps=T, beta_schedule=schedule)
+    return diff.eval()
+
+
+# ------------------------------------------------------------------------------- sections
+def gen_schedules():
+    out = {}
+    for name, T in cases.SCHEDULE_CASES:
+        unet = ref_unet.TemporalUnet(6, dim=32, dim_mults=(1, 2))
+        d = GaussianDiffusion(unet, 32, 4, 2, n_timesteps=T, beta_schedule=name)
+        for k, v in d.state_dict().items():
+            if not k.startswith("model."):
+                out[f"{name}_{T}.{k}"] = v.numpy()
+    save("schedules", **out)
+
+
+def gen_pointwise():
+    out = {}
+    for dim in cases.SINUSOID_DIMS:
+        emb = ref_unet.SinusoidalPosEmb(dim)
+        out[f"sinusoid_{dim}"] = emb(torch.tensor(cases.SINUSOID_T)).numpy()
+    grid = np.concatenate([np.linspace(-30, 30, 241), [-100.0, 19.99, 20.0, 20.01, 25.0, 88.0]])
+    out["mish_in"] = grid.astype(np.float32)
+    out["mish_out"] = torch.nn.Mish()(torch.from_numpy(out["mish_in"])).numpy()
+    save("pointwise", **out)
+
+
+def gen_units():
+    out = {}
+    for name, kind, ci, co, L, B in cases.UNIT_CASES:
+        w = cases.unit_weights(name, kind, ci, co)
+        x, temb = cases.unit_inputs(name, ci, L, B)
+        xt, tt = torch.from_numpy(x), torch.from_numpy(temb)
+        with torch.no_grad():
+            if kind == "conv_block":
+                m = ref_unet.Conv1dBlock(ci, co, kernel_size=5)
+                load_into(m, w)
+                y = m(xt)
+            elif kind == "res_block":
+                m = ref_unet.ResidualTemporalBlock(ci, co, embed_dim=cases.UNIT_TIME_DIM)
+                load_into(m, w)
+                y = m(xt, tt)
+            elif kind == "down":
+                m = ref_unet.Downsample1d(ci)
+                load_into(m, w)
+                y = m(xt)
+            else:
+                m = ref_unet.Upsample1d(ci)
+                load_into(m, w)
+                y = m(xt)
+        out[name] = y.numpy()
+    save("units", **out)
+
+
+def gen_forward(only_small: bool = False):
+    for case, net, B, t in cases.FORWARD_CASES:
+        if only_small and net in ("halfcheetah", "door"):
+            continue
+        print(f"  forward {case} ...")
+        od, ad, td, dim, mults = cases.net_dims(net)
+        unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults)).eval()
+        load_into(unet, cases.net_weights(net))
+        x = torch.from_numpy(cases.forward_input(case, net, B))
+        tt = torch.full((B,), t, dtype=torch.long)
+        out = {}
+        with torch.no_grad():
+            if net.startswith("tiny"):
+                # per-stage intermediates via forward hooks (outputs of whole stages)
+                feats = {}
+                hooks = []
+                for i, stage in enumerate(unet.downs):
+                    hooks.append(stage[1].register_forward_hook(
+                        lambda m, a, o, i=i: feats.__setitem__(f"downs.{i}", o.numpy().copy())))
+                hooks.append(unet.mid_block2.register_forward_hook(
+                    lambda m, a, o: feats.__setitem__("mid", o.numpy().copy())))
+                for j, stage in enumerate(unet.ups):
+                    hooks.append(stage[2].register_forward_hook(
+                        lambda m, a, o, j=j: feats.__setitem__(f"ups.{j}", o.numpy().copy())))
+                hooks.append(unet.time_mlp.register_forward_hook(
+                    lambda m, a, o: feats.__setitem__("temb", o.numpy().copy())))
+                y = unet(x, tt)
+                for h in hooks:
+                    h.remove()
+                out.update({f"tap.{k}": v for k, v in feats.items()})
+            else:
+                y = unet(x, tt)
+            # fp64 truth with the reference modules themselves (sinusoid stays fp32)
+            u64 = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults)).eval()
+            load_into(u64, cases.net_weights(net))
+            u64 = u64.double()
+            pos = u64.time_mlp[0]
+            orig = pos.forward
+            pos.forward = lambda tt_, orig=orig: orig(tt_).double()
+            y64 = u64(x.double(), tt)
+        out["eps"] = y.numpy()
+        out["eps_fp64"] = y64.numpy()
+        save(case, **out)
+        del unet, u64
+
+
+def gen_loops():
+    for case, net, T, n_steps, B, conditioned, schedule in cases.LOOP_CASES:
+        print(f"  loop {case} ...")
+        diff = build_reference(net, T, schedule)
+        diff.n_timesteps = n_steps                     # evaluate.py:350-353 semantics
+        noise = cases.loop_noise(case, net, n_steps, B)
+        out = {}
+        if conditioned:
+            pol = ref_pol.GuidedPolicy(diff, normalizer=None)
+            cond = {0: torch.from_numpy(cases.loop_condition(case, net))}
+            with injected_noise(noise):
+                x = pol.sample_loop(batch_size=B, conditions=cond)
+            # one isolated step (first iteration) for single-step parity
+            x0 = torch.from_numpy(noise[0]).clone()
+            x0[:, 0] = cond[0]
+            with injected_noise(noise[1:2]):
+                step = pol.p_sample_with_guidance(
+                    x0.clone(), torch.full((B,), n_steps - 1, dtype=torch.long), cond)
+        else:
+            with injected_noise(noise):
+                x = diff.p_sample_loop((B, cases.H, diff.transition_dim))
+            x0 = torch.from_numpy(noise[0]).clone()
+            with injected_noise(noise[1:2]):
+                step = diff.p_sample(x0.clone(), torch.full((B,), n_steps - 1, dtype=torch.long))
+        with torch.no_grad():
+            mean, logvar = diff.p_mean_variance(
+                x0.clone(), torch.full((B,), n_steps - 1, dtype=torch.long))
+        out.update(x_final=x.numpy(), first_step=step.numpy(), first_mean=mean.numpy(),
+                   first_logvar=logvar.numpy())
+        save(case, **out)
+
+
+class ValueNet(torch.nn.Module):
+    def __init__(self, od):
+        super().__init__()
+        vw = cases.value_net_weights(od)
+        self.w1 = torch.nn.Parameter(torch.from_numpy(vw["w1"]))
+        self.b1 = torch.nn.Parameter(torch.from_numpy(vw["b1"]))
+        self.w2 = torch.nn.Parameter(torch.from_numpy(vw["w2"]))
+        self.b2 = torch.nn.Parameter(torch.from_numpy(vw["b2"]))
+
+    def forward(self, obs):
+        h = torch.tanh(torch.nn.functional.linear(obs, self.w1, self.b1))
+        return torch.nn.functional.linear(h, self.w2, self.b2)
+
+
+def gen_guidance():
+    for case, net, T, B, gw in cases.GUIDE_CASES:
+        print(f"  guidance {case} ...")
+        diff = build_reference(net, T)
+        od = diff.observation_dim
+        pol = ref_pol.ValueGuidedPolicy(diff, None, ValueNet(od), guide_weight=gw)
+        noise = cases.loop_noise(case, net, T, B)
+        cond = {0: torch.from_numpy(cases.loop_condition(case, net))}
+        with injected_noise(noise):
+            x = pol.sample_loop(batch_size=B, conditions=cond)
+        x0 = torch.from_numpy(noise[0]).clone()
+        x0[:, 0] = cond[0]
+        tt = torch.full((B,), T - 1, dtype=torch.long)
+        xg = x0.clone().requires_grad_(True)
+        grad = torch.autograd.grad(pol.guide_fn(xg, tt).sum(), xg)[0]
+        with injected_noise(noise[1:2]):
+            step = pol.p_sample_with_guidance(x0.clone(), tt, cond)
+        save(case, x_final=x.numpy(), first_step=step.numpy(), first_grad=grad.numpy())
+
+
+def gen_projection():
+    out = {}
+    from oracle.projection import double_integrator
+    for case, dt, Hh in cases.PROJ_MATRIX_CASES:
+        A, B = double_integrator(dt)
+        P = ProjectionMatrixBuilder(A, B, 4, 2).get_projection_matrix(Hh)
+        out[case] = P.numpy()
+    # apply_projection on the H=32, dt=0.1 projector
+    A, B = double_integrator(0.1)
+    P = ProjectionMatrixBuilder(A, B, 4, 2).get_projection_matrix(cases.H)
+    diff = build_reference("tiny", 100)
+    norm = cases.NormalizerStub(4, 2)
+    for sched in cases.PROJ_SCHEDULES:
+        pol = ref_pol.DynamicsAwarePolicy(
+            diff, projection_matrix=P, normalizer=norm, state_dim=4, observation_dim=4,
+            action_dim=2, horizon=cases.H, projection_schedule=sched,
+            projection_strength=cases.PROJ_STRENGTH)
+        for t in cases.PROJ_T:
+            x = torch.from_numpy(cases.projection_input(f"proj_{sched}_{t}"))
+            out[f"apply_{sched}_{t}"] = pol.apply_projection(x.clone(), t).numpy()
+            out[f"alpha_{sched}_{t}"] = np.float64(pol._get_projection_alpha(t))
+    save("projection", **out)
+
+
+def gen_glue():
+    """get_action call sequences (policies.py:193-223): returned actions + buffer sizes."""
+    out = {}
+    diff = build_reference("tiny", 20)
+    norm = cases.NormalizerStub(4, 2)
+    obs = cases.glue_observations()
+    from dynamics_aware_diffusion_amd.utils import synth
+    for ah in cases.ACTION_HORIZONS:
+        pol = ref_pol.GuidedPolicy(diff, norm, action_horizon=ah)
+        acts, sizes, plans = [], [], 0
+        for i in range(cases.N_GET_ACTION_CALLS):
+            if len(pol.action_buffer) == 0:
+                stack = synth.normal_like(52, f"glue.ah{ah}.plan{plans}", (21, 1, cases.H, 6))
+                plans += 1
+                with injected_noise(stack):
+                    a = pol.get_action(obs[i])
+            else:
+                a = pol.get_action(obs[i])
+            acts.append(a)
+            sizes.append(len(pol.action_buffer))
+        out[f"actions_ah{ah}"] = np.stack(acts)
+        out[f"buffer_ah{ah}"] = np.array(sizes)
+        out[f"plans_ah{ah}"] = np.int64(plans)
+    save("glue", **out)
+
+
+SECTIONS = {
+    "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
+    "forward": gen_forward, "loops": gen_loops, "guidance": gen_guidance,
+    "projection": gen_projection, "glue": gen_glue,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    for name, fn in SECTIONS.items():
+        if args.only and not name.startswith(args.only):
+            continue
+        print(f"[{name}]")
+        fn()

@@ -1,0 +1,168 @@
+"""Pin the CPU oracle against golden vectors made by the real reference
+(tests/golden/make_golden.py).  CPU only; runs in the `-m "not gpu"` suite."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as od
+from oracle import projection as op
+from tests.golden import cases
+from tests.util import as_torch, golden, max_abs, net_weights_torch
+
+TOL = 1e-6          # CPU restatement <= 1e-6 abs
+
+
+def test_schedules_bitwise():
+    g = golden("schedules")
+    for name, T in cases.SCHEDULE_CASES:
+        bufs = od.schedule_buffers(name, T)
+        assert len(bufs) == 12
+        for k, v in bufs.items():
+            ref = g[f"{name}_{T}.{k}"]
+            assert v.dtype == torch.float32 and v.shape == (T,)
+            assert np.array_equal(v.numpy(), ref), (name, T, k)
+    with pytest.raises(ValueError):
+        od.beta_schedule("sigmoid", 10)
+
+
+def test_sinusoid_and_mish():
+    g = golden("pointwise")
+    for dim in cases.SINUSOID_DIMS:
+        e = od.sinusoidal_embedding(torch.tensor(cases.SINUSOID_T), dim)
+        assert np.array_equal(e.numpy(), g[f"sinusoid_{dim}"])
+    y = torch.nn.functional.mish(torch.from_numpy(g["mish_in"]))
+    assert np.array_equal(y.numpy(), g["mish_out"])
+
+
+@pytest.mark.parametrize("case", cases.UNIT_CASES, ids=lambda c: c[0])
+def test_unit_layers(case):
+    name, kind, ci, co, L, B = case
+    g = golden("units")
+    w = as_torch(cases.unit_weights(name, kind, ci, co))
+    x, temb = cases.unit_inputs(name, ci, L, B)
+    x, temb = torch.from_numpy(x), torch.from_numpy(temb)
+    F = torch.nn.functional
+    if kind == "conv_block":
+        y = od.conv_block({"b." + k: v for k, v in w.items()}, "b", x)
+    elif kind == "res_block":
+        y = od.residual_block({"r." + k: v for k, v in w.items()}, "r", x, temb)
+    elif kind == "down":
+        y = F.conv1d(x, w["conv.weight"], w["conv.bias"], stride=2, padding=1)
+    else:
+        y = F.conv_transpose1d(x, w["conv.weight"], w["conv.bias"], stride=2, padding=1)
+    assert max_abs(y.numpy(), g[name]) <= TOL
+
+
+@pytest.mark.parametrize("case", [c for c in cases.FORWARD_CASES if c[1] in ("tiny", "tiny4", "pointmaze")],
+                         ids=lambda c: c[0])
+def test_unet_forward(case):
+    name, net, B, t = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    x = torch.from_numpy(cases.forward_input(name, net, B))
+    taps = {}
+    with torch.no_grad():
+        eps = od.unet_forward(w, x, torch.full((B,), t, dtype=torch.long), taps)
+    assert max_abs(eps.numpy(), g["eps"]) <= TOL
+    for k in g.files:
+        if k.startswith("tap."):
+            assert max_abs(taps[k[4:]].numpy(), g[k]) <= 2e-6, k
+    # fp64 run of the restatement vs fp64 run of the reference modules
+    with torch.no_grad():
+        eps64 = od.unet_forward(od.cast_weights(w, torch.float64), x.double(),
+                                torch.full((B,), t, dtype=torch.long))
+    assert max_abs(eps64.numpy(), g["eps_fp64"]) <= 1e-12
+
+
+@pytest.mark.parametrize("case", cases.LOOP_CASES, ids=lambda c: c[0])
+def test_sampling_loops(case):
+    name, net, T, n_steps, B, conditioned, schedule = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    sched = od.schedule_buffers(schedule, T)
+    noise = torch.from_numpy(cases.loop_noise(name, net, n_steps, B))
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net))} if conditioned else None
+    x = od.sample_loop(w, sched, noise, n_steps, cond)
+    assert max_abs(x.numpy(), g["x_final"]) <= 5e-6
+    # isolated first step
+    x0 = noise[0].clone()
+    if cond is not None:
+        x0[:, 0] = cond[0]
+    t = torch.full((B,), n_steps - 1, dtype=torch.long)
+    with torch.no_grad():
+        mean, logvar, _ = od.p_mean_variance(w, sched, x0, t)
+        step = od.denoise_step(w, sched, x0, t, noise[1], cond)
+    assert max_abs(mean.numpy(), g["first_mean"]) <= TOL
+    assert np.array_equal(logvar.numpy(), g["first_logvar"])
+    assert max_abs(step.numpy(), g["first_step"]) <= TOL
+
+
+def test_truncated_schedule_out_of_range_raises():
+    """sampling with more steps than the trained schedule fails in gather."""
+    sched = od.schedule_buffers("cosine", 20)
+    w = net_weights_torch("tiny")
+    x = torch.zeros(1, 32, 6)
+    with pytest.raises(RuntimeError):
+        od.p_mean_variance(w, sched, x, torch.full((1,), 25, dtype=torch.long))
+
+
+def _value_fn(od_dim):
+    vw = as_torch(cases.value_net_weights(od_dim))
+    F = torch.nn.functional
+
+    def value(obs):
+        return F.linear(torch.tanh(F.linear(obs, vw["w1"], vw["b1"])), vw["w2"], vw["b2"])
+
+    def guide_fn(x, t):                      # guides/policies.py:264-268
+        return value(x[:, :, :od_dim]).sum(dim=1)
+    return guide_fn
+
+
+@pytest.mark.parametrize("case", cases.GUIDE_CASES, ids=lambda c: c[0])
+def test_value_guidance(case):
+    name, net, T, B, gw = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    sched = od.schedule_buffers("cosine", T)
+    noise = torch.from_numpy(cases.loop_noise(name, net, T, B))
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net))}
+    guide_fn = _value_fn(cases.net_dims(net)[0])
+    x = od.sample_loop(w, sched, noise, T, cond, guide_fn=guide_fn, guide_weight=gw)
+    assert max_abs(x.numpy(), g["x_final"]) <= 5e-6
+    x0 = noise[0].clone()
+    x0[:, 0] = cond[0]
+    t = torch.full((B,), T - 1, dtype=torch.long)
+    grad = od.guide_gradient(guide_fn, x0, t)
+    assert max_abs(grad.numpy(), g["first_grad"]) <= TOL
+    assert np.all(grad.numpy()[:, :, 4:] == 0)           # action channels get no gradient
+    with torch.no_grad():
+        step = od.denoise_step(w, sched, x0, t, noise[1], cond, grad, gw)
+    assert max_abs(step.numpy(), g["first_step"]) <= TOL
+
+
+def test_projection_matrices_and_apply():
+    g = golden("projection")
+    for case, dt, Hh in cases.PROJ_MATRIX_CASES:
+        A, B = op.double_integrator(dt)
+        P = op.projection_matrix(A, B, Hh)
+        assert P.dtype == torch.float32
+        assert max_abs(P.numpy(), g[case]) <= 1e-6
+        assert torch.allclose(P @ P, P, atol=1e-4)       # projection.py:122-133
+    A, B = op.double_integrator(0.1)
+    P = op.projection_matrix(A, B, cases.H)
+    norm = cases.NormalizerStub(4, 2)
+    stats = [torch.from_numpy(v) for v in (norm.obs_mean, norm.obs_std, norm.action_mean, norm.action_std)]
+    betas = od.schedule_buffers("cosine", 100)["betas"]
+    for sched in cases.PROJ_SCHEDULES:
+        for t in cases.PROJ_T:
+            alpha = op.projection_alpha(sched, cases.PROJ_STRENGTH, t, 100, betas)
+            assert abs(alpha - float(g[f"alpha_{sched}_{t}"])) <= 1e-12
+            x = torch.from_numpy(cases.projection_input(f"proj_{sched}_{t}"))
+            y = op.apply_projection(x, P, alpha, 4, 4, *stats)
+            assert max_abs(y.numpy(), g[f"apply_{sched}_{t}"]) <= 2e-6
+    with pytest.raises(ValueError):
+        op.projection_alpha("cubic", 1.0, 0, 100, betas)
+    # observation_dim > state_dim: the reference raises on the broadcast (Appendix D.8)
+    with pytest.raises(RuntimeError):
+        op.apply_projection(torch.zeros(2, 32, 8), P, 0.5, 4, 6,
+                            torch.zeros(6), torch.ones(6), torch.zeros(2), torch.ones(2))
