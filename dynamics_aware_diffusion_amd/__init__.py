@@ -1,0 +1,15 @@
+"""MI355X-native reverse-diffusion planning sampler.
+
+Drop-in for the sampling path of ``m_diffuser`` (darshangm/dynamics-aware-diffusion):
+``models.TemporalUnet`` / ``models.GaussianDiffusion`` / ``guides.*Policy`` /
+``dynamics.ProjectionMatrixBuilder`` keep the reference's names and signatures; the
+arithmetic runs in ``libdad_hip.so`` (hand-written gfx950 kernels, C ABI in
+``include/dad.h``).  No CPU fallback exists.
+"""
+from . import dynamics, guides, models
+from .guides import DynamicsAwarePolicy, GuidedPolicy, MPCPolicy, ValueGuidedPolicy
+from .models import GaussianDiffusion, TemporalUnet
+
+__version__ = "0.1.0"
+__all__ = ["models", "guides", "dynamics", "TemporalUnet", "GaussianDiffusion", "GuidedPolicy",
+           "MPCPolicy", "ValueGuidedPolicy", "DynamicsAwarePolicy"]

@@ -1,0 +1,334 @@
+"""ctypes binding of ``libdad_hip.so`` (C ABI: ``include/dad.h``) and the thin engine object
+the API mirror classes drive.
+
+There is deliberately NO fallback: if the library is missing or a tensor is not on a ROCm
+device the calls raise.  torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Mapping, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdad_hip.so")
+
+DAD_MAX_LEVELS = 8
+DAD_E_RANGE = -5
+
+
+class DadCfg(C.Structure):
+    _fields_ = [
+        ("transition_dim", C.c_int32), ("dim", C.c_int32), ("time_dim", C.c_int32),
+        ("n_levels", C.c_int32), ("channels", C.c_int32 * DAD_MAX_LEVELS),
+        ("kernel_size", C.c_int32), ("horizon", C.c_int32), ("n_timesteps", C.c_int32),
+        ("predict_epsilon", C.c_int32), ("clip_denoised", C.c_int32),
+    ]
+
+
+class DadStepArgs(C.Structure):
+    _fields_ = [
+        ("noise", C.c_void_p), ("seed", C.c_uint64), ("row_offset", C.c_uint64),
+        ("draw", C.c_uint64), ("cond0", C.c_void_p), ("cond_per_row", C.c_int32),
+        ("guide_grad", C.c_void_p), ("guide_weight", C.c_float),
+        ("mean_out", C.c_void_p), ("eps_out", C.c_void_p),
+    ]
+
+
+class DadProjectArgs(C.Structure):
+    _fields_ = [
+        ("P", C.c_void_p), ("obs_mean", C.c_void_p), ("obs_std", C.c_void_p),
+        ("act_mean", C.c_void_p), ("act_std", C.c_void_p),
+        ("state_dim", C.c_int32), ("observation_dim", C.c_int32), ("action_dim", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); also the list of symbols include/dad.h declares.
+ABI = {
+    "dad_last_error": (C.c_char_p, []),
+    "dad_version": (C.c_char_p, []),
+    "dad_model_create": (C.c_int, [C.POINTER(DadCfg), C.POINTER(C.c_void_p)]),
+    "dad_model_destroy": (None, [C.c_void_p]),
+    "dad_model_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p,
+                                        C.POINTER(C.c_int64), C.c_int32]),
+    "dad_model_load_schedule": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    "dad_model_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t)]),
+    "dad_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dad_denoise_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                   C.POINTER(DadStepArgs), C.c_int32, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
+    "dad_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_uint64, C.c_uint64, C.c_void_p, C.c_int32,
+                                  C.POINTER(DadProjectArgs), C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
+    "dad_project": (C.c_int, [C.POINTER(DadProjectArgs), C.c_float, C.c_void_p, C.c_int32,
+                              C.c_int32, C.c_void_p]),
+    "dad_fill_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64,
+                                  C.c_uint64, C.c_void_p]),
+    "dad_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "dad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libdad_hip.so and type every entry point.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with dynamics_aware_diffusion_amd/csrc/build.sh "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in ABI.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class DadError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libdad_hip error {code}: {message}")
+        self.code = code
+
+
+def _check(lib, rc: int) -> None:
+    if rc != 0:
+        msg = lib.dad_last_error().decode("utf-8", "replace")
+        if rc == DAD_E_RANGE:
+            # the reference raises RuntimeError from gather here (diffusion.py:28)
+            raise DadError(rc, msg)
+        raise DadError(rc, msg)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_device(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a ROCm device (got {t.device}); the HIP engine "
+                           "has no CPU path")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous float32 (got {t.dtype}, "
+                           f"contiguous={t.is_contiguous()})")
+
+
+SCHEDULE_KEYS = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                 "posterior_mean_coef1", "posterior_mean_coef2",
+                 "posterior_log_variance_clipped")
+
+
+class HipEngine:
+    """One ``dad_model`` on one device: packed weights, time tables, workspaces."""
+
+    def __init__(self, *, transition_dim: int, dim: int, channels: Sequence[int], horizon: int,
+                 n_timesteps: int, time_dim: Optional[int] = None, kernel_size: int = 5,
+                 predict_epsilon: bool = True, clip_denoised: bool = True,
+                 device: torch.device | str = "cuda"):
+        self.lib = load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipEngine needs a ROCm device; there is no CPU path")
+        cfg = DadCfg()
+        cfg.transition_dim = transition_dim
+        cfg.dim = dim
+        cfg.time_dim = time_dim or dim
+        cfg.n_levels = len(channels)
+        for i, ch in enumerate(channels):
+            cfg.channels[i] = int(ch)
+        cfg.kernel_size = kernel_size
+        cfg.horizon = horizon
+        cfg.n_timesteps = n_timesteps
+        cfg.predict_epsilon = int(predict_epsilon)
+        cfg.clip_denoised = int(clip_denoised)
+        self.cfg = cfg
+        self.horizon = horizon
+        self.transition_dim = transition_dim
+        self.n_timesteps = n_timesteps
+        handle = C.c_void_p()
+        _check(self.lib, self.lib.dad_model_create(C.byref(cfg), C.byref(handle)))
+        self._h = handle
+        self._ws: Dict[int, torch.Tensor] = {}
+        self.ready = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self.lib.dad_model_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ weights
+    def load(self, unet_state: Mapping[str, torch.Tensor],
+             schedule: Mapping[str, torch.Tensor]) -> None:
+        """Upload every denoiser tensor (reference state_dict keys without ``model.``) and
+        the five schedule buffers, then build tables and the launch plan."""
+        keep = []
+        for key, t in unet_state.items():
+            h = t.detach().to("cpu", torch.float32).contiguous()
+            keep.append(h)
+            shape = (C.c_int64 * h.dim())(*h.shape)
+            _check(self.lib, self.lib.dad_model_load_weight(
+                self._h, key.encode(), h.data_ptr(), shape, h.dim()))
+        bufs = []
+        for k in SCHEDULE_KEYS:
+            b = schedule[k].detach().to("cpu", torch.float32).contiguous()
+            if b.numel() != self.n_timesteps:
+                raise ValueError(f"schedule buffer {k} has {b.numel()} entries, expected "
+                                 f"{self.n_timesteps}")
+            bufs.append(b)
+        _check(self.lib, self.lib.dad_model_load_schedule(self._h, *[b.data_ptr() for b in bufs]))
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_model_finalize(self._h, self._stream()))
+        self.ready = True
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        ws = self._ws.get(batch)
+        if ws is None:
+            n = C.c_size_t()
+            _check(self.lib, self.lib.dad_workspace_bytes(self._h, batch, C.byref(n)))
+            ws = torch.empty(max(n.value, 4) // 4, dtype=torch.float32, device=self.device)
+            self._ws[batch] = ws
+        return ws
+
+    def _traj(self, x: torch.Tensor, name: str = "x") -> int:
+        _require_device(x, name)
+        if x.dim() != 3 or x.shape[1] != self.horizon or x.shape[2] != self.transition_dim:
+            raise RuntimeError(f"{name} must be (B, {self.horizon}, {self.transition_dim}), "
+                               f"got {tuple(x.shape)}")
+        return int(x.shape[0])
+
+    # ------------------------------------------------------------------ compute
+    def unet_forward(self, x: torch.Tensor, t: int) -> torch.Tensor:
+        B = self._traj(x)
+        out = torch.empty_like(x)
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_unet_forward(
+                self._h, x.data_ptr(), int(t), out.data_ptr(), B, ws.data_ptr(),
+                ws.numel() * 4, self._stream()))
+        return out
+
+    def denoise_step(self, x: torch.Tensor, t: int, *, noise: Optional[torch.Tensor] = None,
+                     seed: int = 0, row_offset: int = 0, draw: int = 0,
+                     cond0: Optional[torch.Tensor] = None,
+                     guide_grad: Optional[torch.Tensor] = None, guide_weight: float = 0.0,
+                     mean_out: Optional[torch.Tensor] = None,
+                     eps_out: Optional[torch.Tensor] = None, update_x: bool = True) -> None:
+        """In-place reverse step on ``x`` (see dad_denoise_step in include/dad.h)."""
+        B = self._traj(x)
+        a = DadStepArgs()
+        for name, ten in (("noise", noise), ("guide_grad", guide_grad), ("mean_out", mean_out),
+                          ("eps_out", eps_out)):
+            if ten is not None:
+                if self._traj(ten, name) != B:
+                    raise RuntimeError(f"{name} batch mismatch")
+                setattr(a, name, ten.data_ptr())
+        a.seed, a.row_offset, a.draw = int(seed), int(row_offset), int(draw)
+        if cond0 is not None:
+            _require_device(cond0, "cond0")
+            rows = cond0.reshape(-1, self.transition_dim).shape[0]
+            if rows not in (1, B):
+                raise RuntimeError(f"cond0 must be (1, td) or (B, td), got {tuple(cond0.shape)}")
+            a.cond0 = cond0.data_ptr()
+            a.cond_per_row = int(rows == B and B > 1)
+        a.guide_weight = float(guide_weight)
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_denoise_step(
+                self._h, x.data_ptr(), int(t), B, C.byref(a), int(not update_x), ws.data_ptr(),
+                ws.numel() * 4, self._stream()))
+
+    def sample_loop(self, x: torch.Tensor, n_steps: int, *,
+                    noise_stack: Optional[torch.Tensor] = None, seed: int = 0,
+                    row_offset: int = 0, cond0: Optional[torch.Tensor] = None,
+                    projection: Optional["ProjectionState"] = None,
+                    proj_alphas: Optional[Sequence[float]] = None,
+                    use_graph: bool = False) -> None:
+        B = self._traj(x)
+        cond_ptr, per_row = None, 0
+        if cond0 is not None:
+            _require_device(cond0, "cond0")
+            rows = cond0.reshape(-1, self.transition_dim).shape[0]
+            if rows not in (1, B):
+                raise RuntimeError(f"cond0 must be (1, td) or (B, td), got {tuple(cond0.shape)}")
+            cond_ptr, per_row = cond0.data_ptr(), int(rows == B and B > 1)
+        if noise_stack is not None:
+            _require_device(noise_stack, "noise_stack")
+            if tuple(noise_stack.shape) != (n_steps, B, self.horizon, self.transition_dim):
+                raise RuntimeError("noise_stack must be (n_steps, B, H, td)")
+        pa, alphas = None, None
+        if projection is not None:
+            pa = C.byref(projection.args)
+            alphas = (C.c_float * self.n_timesteps)(*[float(a) for a in proj_alphas])
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_sample_loop(
+                self._h, x.data_ptr(), int(n_steps), B, _ptr(noise_stack), int(seed),
+                int(row_offset), cond_ptr, per_row, pa, alphas, int(use_graph), ws.data_ptr(),
+                ws.numel() * 4, self._stream()))
+
+    def fill_normal(self, x: torch.Tensor, seed: int, row_offset: int = 0, draw: int = 0) -> None:
+        _require_device(x, "x")
+        B = int(x.shape[0])
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_fill_normal(
+                x.data_ptr(), B, x.numel() // B, int(seed), int(row_offset), int(draw),
+                self._stream()))
+
+    # ------------------------------------------------------------------ profiling
+    def profile_enable(self, on: bool) -> None:
+        _check(self.lib, self.lib.dad_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        _check(self.lib, self.lib.dad_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+
+class ProjectionState:
+    """Device-resident projector + normaliser statistics for dad_project."""
+
+    def __init__(self, P: torch.Tensor, obs_mean, obs_std, act_mean, act_std, state_dim: int,
+                 observation_dim: int, action_dim: int, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("projection kernel needs a ROCm device; there is no CPU path")
+
+        def put(v):
+            return torch.as_tensor(v, dtype=torch.float32).contiguous().to(dev)
+
+        self.P = put(P)
+        self.obs_mean, self.obs_std = put(obs_mean), put(obs_std)
+        self.act_mean, self.act_std = put(act_mean), put(act_std)
+        a = DadProjectArgs()
+        a.P = self.P.data_ptr()
+        a.obs_mean, a.obs_std = self.obs_mean.data_ptr(), self.obs_std.data_ptr()
+        a.act_mean, a.act_std = self.act_mean.data_ptr(), self.act_std.data_ptr()
+        a.state_dim, a.observation_dim, a.action_dim = state_dim, observation_dim, action_dim
+        self.args = a
+        self.device = dev
+
+    def apply(self, x: torch.Tensor, alpha: float) -> None:
+        _require_device(x, "x")
+        lib = load_library()
+        with torch.cuda.device(self.device):
+            _check(lib, lib.dad_project(C.byref(self.args), float(alpha), x.data_ptr(),
+                                        int(x.shape[0]), int(x.shape[1]),
+                                        torch.cuda.current_stream(self.device).cuda_stream))

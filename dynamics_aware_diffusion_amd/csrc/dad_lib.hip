@@ -1,0 +1,851 @@
+// dad_lib.hip — host side of libdad_hip.so: model state, weight packing, launch plan and
+// the C ABI declared in include/dad.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/dad.h"
+#include "conv_gemm.hpp"
+#include "pointwise.hpp"
+
+namespace {
+
+thread_local char g_err[1024] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(DAD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                            \
+    } while (0)
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+enum ConvKind { CONV_K5 = 0, CONV_1X1 = 1, CONV_DOWN = 2, CONV_UP = 3 };
+
+// One conv-GEMM launch of the plan.  Buffer ids index Plan::bufs; -1 = none,
+// -2 = the external (B,H,td) trajectory tensor.
+struct ConvOp {
+    std::string name;        // weight key prefix, e.g. "downs.0.0.blocks.0.block.0"
+    std::string norm;        // GroupNorm key prefix or ""
+    ConvKind kind;
+    int taps, stride;
+    int cin0, cin1, cin_pad;
+    int cout;                // real output channels
+    int M;                   // GEMM rows (2*cout for CONV_UP)
+    int Lin, Lout;           // GEMM per-sample lengths (CONV_UP: Lout == Lin, stores 2*Lin)
+    int src0, src1, dst, res;
+    int temb_off;            // offset into the per-t table, or -1
+    // device tensors (owned by the model)
+    float* d_w = nullptr;
+    float* d_bias = nullptr;
+    float* d_gamma = nullptr;
+    float* d_beta = nullptr;
+    double flops_per_sample = 0;
+};
+
+struct Buf {
+    long per_sample;   // floats per batch row
+    long offset;       // floats per batch row, from workspace start
+};
+
+struct Plan {
+    std::vector<ConvOp> convs;
+    std::vector<Buf> bufs;
+    long floats_per_sample = 0;
+    int final_act = -1;       // buffer holding final_conv[0] output
+    int temb_width = 0;       // sum of C_out over residual blocks
+};
+
+struct TileCfg { int BM, BN, WM, WN, KC; };
+const TileCfg kTiles[] = {
+    {32, 64, 1, 2, 16},    // 0
+    {64, 64, 2, 2, 16},    // 1
+    {128, 64, 4, 2, 8},    // 2
+    {256, 64, 4, 2, 8},    // 3
+};
+
+struct GraphKey {
+    const void* x; const void* noise; const void* cond; const void* ws; const void* P;
+    int n_steps, batch, cond_per_row;
+    bool operator<(const GraphKey& o) const {
+        return std::memcmp(this, &o, sizeof(GraphKey)) < 0;
+    }
+};
+
+}  // namespace
+
+struct dad_model {
+    dad_cfg cfg;
+    std::map<std::string, HostTensor> raw;
+    std::map<std::string, std::vector<int64_t>> expected;     // key -> shape
+    Plan plan;
+    bool finalized = false;
+    std::vector<float> sched[5];                               // host schedule scalars
+    bool have_sched = false;
+    // device
+    float* d_temb_table = nullptr;    // [T][temb_width]
+    float* d_final_w = nullptr;       // [td][dim]
+    float* d_final_b = nullptr;
+    uint64_t* d_rng = nullptr;
+    std::vector<void*> owned;         // every hipMalloc to free
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double prof_flops = 0;
+    // graphs
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;
+};
+
+namespace {
+
+using dad::ConvParams;
+
+int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ----------------------------------------------------------------------------- planning
+struct Allocator {
+    std::vector<Buf>& bufs;
+    std::vector<bool> in_use;
+    explicit Allocator(std::vector<Buf>& b) : bufs(b) {}
+    int get(long per_sample) {
+        int best = -1;
+        for (size_t i = 0; i < bufs.size(); ++i)
+            if (!in_use[i] && bufs[i].per_sample >= per_sample &&
+                (best < 0 || bufs[i].per_sample < bufs[best].per_sample))
+                best = (int)i;
+        if (best < 0) {
+            bufs.push_back({per_sample, 0});
+            in_use.push_back(false);
+            best = (int)bufs.size() - 1;
+        }
+        in_use[best] = true;
+        return best;
+    }
+    void put(int id) { if (id >= 0) in_use[id] = false; }
+};
+
+void expect(dad_model* m, const std::string& key, std::vector<int64_t> shape) {
+    m->expected[key] = std::move(shape);
+}
+
+// Emits the launch plan of TemporalUnet.forward (temporal_unet.py:199-241) including the
+// reference's always-upsample decoder and unused level-0 skip.
+int build_plan(dad_model* m) {
+    const dad_cfg& c = m->cfg;
+    Plan& P = m->plan;
+    Allocator A(P.bufs);
+    const int k = c.kernel_size;
+    const int tdm = c.time_dim;
+    int temb_off = 0;
+
+    auto conv = [&](const std::string& name, const std::string& norm, ConvKind kind, int src0,
+                    int src1, int cin0, int cin1, int cout, int Lin, int dst, int res,
+                    int toff) {
+        ConvOp op;
+        op.name = name; op.norm = norm; op.kind = kind;
+        op.cin0 = cin0; op.cin1 = cin1; op.cin_pad = (cin0 + cin1 + 7) / 8 * 8;
+        op.cout = cout; op.src0 = src0; op.src1 = src1; op.dst = dst; op.res = res;
+        op.temb_off = toff; op.Lin = Lin;
+        const int cin = cin0 + cin1;
+        switch (kind) {
+            case CONV_K5: op.taps = k; op.stride = 1; op.M = cout; op.Lout = Lin;
+                expect(m, name + ".weight", {cout, cin, k});
+                op.flops_per_sample = 2.0 * cout * cin * k * Lin; break;
+            case CONV_1X1: op.taps = 1; op.stride = 1; op.M = cout; op.Lout = Lin;
+                expect(m, name + ".weight", {cout, cin, 1});
+                op.flops_per_sample = 2.0 * cout * cin * Lin; break;
+            case CONV_DOWN: op.taps = 3; op.stride = 2; op.M = cout; op.Lout = Lin / 2;
+                expect(m, name + ".weight", {cout, cin, 3});
+                op.flops_per_sample = 2.0 * cout * cin * 3 * (Lin / 2); break;
+            case CONV_UP: op.taps = 3; op.stride = 1; op.M = 2 * cout; op.Lout = Lin;
+                expect(m, name + ".weight", {cin, cout, 4});
+                op.flops_per_sample = 2.0 * cout * cin * 4 * Lin; break;   // algorithmic
+        }
+        expect(m, name + ".bias", {cout});
+        if (!norm.empty()) {
+            expect(m, norm + ".weight", {cout});
+            expect(m, norm + ".bias", {cout});
+        }
+        P.convs.push_back(op);
+    };
+
+    auto res_block = [&](const std::string& base, int in0, int in1, int cin0, int cin1, int cout,
+                         int L) -> int {
+        const int cin = cin0 + cin1;
+        if (cin == cout && in1 >= 0) return -100;   // identity residual of a concat: unsupported
+        const int toff = temb_off;
+        temb_off += cout;
+        expect(m, base + ".time_mlp.1.weight", {cout, tdm});
+        expect(m, base + ".time_mlp.1.bias", {cout});
+        const int a0 = A.get((long)cout * L);
+        conv(base + ".blocks.0.block.0", base + ".blocks.0.block.1", CONV_K5, in0, in1, cin0, cin1,
+             cout, L, a0, -1, toff);
+        int res = -1;
+        if (cin != cout) {
+            res = A.get((long)cout * L);
+            conv(base + ".residual_conv", "", CONV_1X1, in0, in1, cin0, cin1, cout, L, res, -1, -1);
+        }
+        const int out = A.get((long)cout * L);
+        conv(base + ".blocks.1.block.0", base + ".blocks.1.block.1", CONV_K5, a0, -1, cout, 0,
+             cout, L, out, res >= 0 ? res : in0, -1);
+        A.put(a0);
+        A.put(res);
+        return out;
+    };
+
+    expect(m, "time_mlp.1.weight", {4 * tdm, c.dim});
+    expect(m, "time_mlp.1.bias", {4 * tdm});
+    expect(m, "time_mlp.3.weight", {tdm, 4 * tdm});
+    expect(m, "time_mlp.3.bias", {tdm});
+
+    const int nl = c.n_levels;
+    int L = c.horizon;
+    int x = -2, cx = c.transition_dim;
+    std::vector<int> skips, skip_ch;
+    for (int i = 0; i < nl; ++i) {
+        const int co = c.channels[i];
+        const std::string b = "downs." + std::to_string(i);
+        const int h1 = res_block(b + ".0", x, -1, cx, 0, co, L);
+        if (x >= 0) A.put(x);
+        const int h2 = res_block(b + ".1", h1, -1, co, 0, co, L);
+        A.put(h1);
+        skips.push_back(h2);
+        skip_ch.push_back(co);
+        if (i < nl - 1) {
+            const int d = A.get((long)co * (L / 2));
+            conv(b + ".2.conv", "", CONV_DOWN, h2, -1, co, 0, co, L, d, -1, -1);
+            L /= 2;
+            x = d;
+            if (i == 0) A.put(h2);   // level-0 skip is pushed but never popped (F8)
+        } else {
+            x = h2;
+        }
+        cx = co;
+    }
+    const int cm = c.channels[nl - 1];
+    const bool x_is_skip = true;   // x aliases skips.back() (last level has no downsample)
+    const int m1 = res_block("mid_block1", x, -1, cm, 0, cm, L);
+    (void)x_is_skip;
+    const int m2 = res_block("mid_block2", m1, -1, cm, 0, cm, L);
+    A.put(m1);
+    x = m2;
+    cx = cm;
+    for (int j = 0; j < nl - 1; ++j) {
+        const int lvl = nl - 1 - j;                 // level whose skip is popped
+        const int skip = skips[lvl];
+        const int cs = skip_ch[lvl];
+        const int co = c.channels[lvl - 1];
+        const std::string b = "ups." + std::to_string(j);
+        const int u1 = res_block(b + ".0", x, skip, cx, cs, co, L);
+        if (u1 == -100)
+            return fail(DAD_E_INVALID, "decoder stage %d: identity residual over a channel concat "
+                        "(2*%d -> %d) is not supported", j, cx, co);
+        A.put(x);
+        A.put(skip);
+        const int u2 = res_block(b + ".1", u1, -1, co, 0, co, L);
+        A.put(u1);
+        const int up = A.get((long)co * (2 * L));
+        conv(b + ".2.conv", "", CONV_UP, u2, -1, co, 0, co, L, up, -1, -1);
+        A.put(u2);
+        L *= 2;
+        x = up;
+        cx = co;
+    }
+    if (nl == 1) { /* x == skips[0]; nothing popped */ }
+    if (cx != c.dim)
+        return fail(DAD_E_INVALID, "final_conv expects %d channels but the decoder ends with %d "
+                    "(reference requires dim_mults[0] == 1)", c.dim, cx);
+    const int f = A.get((long)c.dim * L);
+    conv("final_conv.0.block.0", "final_conv.0.block.1", CONV_K5, x, -1, cx, 0, c.dim, L, f, -1, -1);
+    P.final_act = f;
+    expect(m, "final_conv.1.weight", {c.transition_dim, c.dim, 1});
+    expect(m, "final_conv.1.bias", {c.transition_dim});
+    P.temb_width = temb_off;
+
+    long off = 0;
+    for (auto& b : P.bufs) {
+        b.offset = off;
+        off += (b.per_sample + 3) / 4 * 4;
+    }
+    P.floats_per_sample = off;
+    return DAD_OK;
+}
+
+// ------------------------------------------------------------------------------ packing
+// Conv1d weight (co, ci, k)  ->  [ci_pad/8][k][8][M]
+std::vector<float> pack_conv(const HostTensor& w, int cin_pad, int taps) {
+    const int co = (int)w.shape[0], ci = (int)w.shape[1], k = (int)w.shape[2];
+    std::vector<float> out((size_t)cin_pad * taps * co, 0.0f);
+    for (int o = 0; o < co; ++o)
+        for (int i = 0; i < ci; ++i)
+            for (int t = 0; t < k; ++t) {
+                const size_t row = ((size_t)(i / 8) * taps + t) * 8 + (i & 7);
+                out[row * co + o] = w.data[((size_t)o * ci + i) * k + t];
+            }
+    return out;
+}
+
+// ConvTranspose1d weight (ci, co, 4), stride 2, pad 1:
+//   y[co, 2j]   = sum_ci W[ci,co,3] x[ci,j-1] + W[ci,co,1] x[ci,j]
+//   y[co, 2j+1] = sum_ci W[ci,co,2] x[ci,j]   + W[ci,co,0] x[ci,j+1]
+// packed as a 3-tap (offsets -1,0,+1) conv with M = 2*co rows: rows [0,co) even phase,
+// rows [co,2co) odd phase.
+std::vector<float> pack_convT(const HostTensor& w, int cin_pad) {
+    const int ci = (int)w.shape[0], co = (int)w.shape[1];
+    const int M = 2 * co;
+    std::vector<float> out((size_t)cin_pad * 3 * M, 0.0f);
+    auto at = [&](int i, int o, int kk) { return w.data[((size_t)i * co + o) * 4 + kk]; };
+    for (int i = 0; i < ci; ++i)
+        for (int o = 0; o < co; ++o) {
+            auto row = [&](int tap) { return ((size_t)(i / 8) * 3 + tap) * 8 + (i & 7); };
+            out[row(0) * M + o] = at(i, o, 3);
+            out[row(1) * M + o] = at(i, o, 1);
+            out[row(1) * M + co + o] = at(i, o, 2);
+            out[row(2) * M + co + o] = at(i, o, 0);
+        }
+    return out;
+}
+
+int upload(dad_model* m, const std::vector<float>& host, float** dev) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(host.size(), 1) * sizeof(float)));
+    m->owned.push_back(p);
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dev = (float*)p;
+    return DAD_OK;
+}
+
+void free_device(dad_model* m) {
+    for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    m->graphs.clear();
+    for (void* p : m->owned) (void)hipFree(p);
+    m->owned.clear();
+    m->d_temb_table = nullptr;
+    m->d_final_w = m->d_final_b = nullptr;
+    m->d_rng = nullptr;
+    for (auto& op : m->plan.convs) op.d_w = op.d_bias = op.d_gamma = op.d_beta = nullptr;
+}
+
+// ------------------------------------------------------------------------- conv launch
+template <int CFG, int TAPS, int STRIDE>
+int launch_conv_t(const ConvParams& p, hipStream_t st) {
+    constexpr int BM = CFG == 0 ? 32 : CFG == 1 ? 64 : CFG == 2 ? 128 : 256;
+    constexpr int BN = 64;
+    constexpr int WM = CFG == 0 ? 1 : CFG == 1 ? 2 : 4;
+    constexpr int WN = 2;
+    constexpr int KC = CFG <= 1 ? 16 : 8;
+    auto kern = dad::conv_gemm_f32<BM, BN, WM, WN, KC, TAPS, STRIDE>;
+    const size_t lds = dad::conv_lds_floats(BM, BN, KC, TAPS, p.Lin, p.Lout) * sizeof(float);
+    const int spt = BN / p.Lout;
+    dim3 grid((p.B + spt - 1) / spt, p.M / BM);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return DAD_OK;
+}
+
+// Every kernel may use up to the full 160 KiB of LDS; raise the dynamic-LDS limit once
+// (not lazily, so that nothing but launches happens under hipGraph capture).
+template <int CFG, int TAPS, int STRIDE>
+hipError_t raise_lds_limit() {
+    constexpr int BM = CFG == 0 ? 32 : CFG == 1 ? 64 : CFG == 2 ? 128 : 256;
+    constexpr int WM = CFG == 0 ? 1 : CFG == 1 ? 2 : 4;
+    constexpr int KC = CFG <= 1 ? 16 : 8;
+    return hipFuncSetAttribute((const void*)dad::conv_gemm_f32<BM, 64, WM, 2, KC, TAPS, STRIDE>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int CFG>
+hipError_t raise_lds_limit_cfg() {
+    hipError_t e;
+    if ((e = raise_lds_limit<CFG, 5, 1>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit<CFG, 3, 2>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit<CFG, 3, 1>()) != hipSuccess) return e;
+    return raise_lds_limit<CFG, 1, 1>();
+}
+int configure_kernels() {
+    static bool done = false;
+    if (done) return DAD_OK;
+    HIP_TRY(raise_lds_limit_cfg<0>());
+    HIP_TRY(raise_lds_limit_cfg<1>());
+    HIP_TRY(raise_lds_limit_cfg<2>());
+    HIP_TRY(raise_lds_limit_cfg<3>());
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel<8>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+    return DAD_OK;
+}
+
+template <int CFG>
+int launch_conv_cfg(const ConvParams& p, int taps, int stride, hipStream_t st) {
+    if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1>(p, st);
+    if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2>(p, st);
+    if (taps == 3 && stride == 1) return launch_conv_t<CFG, 3, 1>(p, st);
+    if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1>(p, st);
+    return fail(DAD_E_INVALID, "unsupported conv taps=%d stride=%d", taps, stride);
+}
+
+// Pick the M tile: it must hold whole GroupNorm groups, divide M (each phase half for the
+// transposed conv), and leave enough workgroups to cover the 256 CUs when it can.
+int choose_tile(const ConvOp& op, int batch) {
+    const int Mrows = op.kind == CONV_UP ? op.M / 2 : op.M;
+    const int cpg = op.norm.empty() ? 1 : op.cout / 8;
+    int best = -1;
+    long best_blocks = -1;
+    for (int cfg = 3; cfg >= 0; --cfg) {
+        const TileCfg& t = kTiles[cfg];
+        if (Mrows % t.BM != 0) continue;
+        if (!op.norm.empty() && (t.BM % cpg != 0)) continue;
+        if (t.BN % op.Lout != 0) continue;
+        const int spt = t.BN / op.Lout;
+        if (!op.norm.empty() && (long)(t.BM / cpg) * spt > 512) continue;
+        const long blocks = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
+        // prefer the largest tile that still yields >= 512 blocks; otherwise most blocks
+        if (best < 0) { best = cfg; best_blocks = blocks; continue; }
+        if (best_blocks < 512 && blocks > best_blocks) { best = cfg; best_blocks = blocks; }
+    }
+    return best;
+}
+
+int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int batch, int t,
+             hipStream_t st) {
+    auto buf = [&](int id) -> float* {
+        return id >= 0 ? ws + m->plan.bufs[id].offset * (long)batch : nullptr;
+    };
+    ConvParams p{};
+    p.src0 = op.src0 == -2 ? xext : buf(op.src0);
+    p.src1 = buf(op.src1);
+    p.src_nlc = op.src0 == -2;
+    p.w = op.d_w; p.bias = op.d_bias; p.gamma = op.d_gamma; p.beta = op.d_beta;
+    p.temb = op.temb_off >= 0 ? m->d_temb_table + (long)t * m->plan.temb_width + op.temb_off : nullptr;
+    p.res = op.res == -2 ? nullptr : buf(op.res);
+    p.dst = buf(op.dst);
+    p.cin0 = op.cin0; p.cin1 = op.cin1; p.cin_pad = op.cin_pad;
+    p.M = op.M; p.cpg = op.norm.empty() ? 0 : op.cout / 8;
+    p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout; p.lshift = ilog2(op.Lout);
+    p.interleave = op.kind == CONV_UP;
+    const int cfg = choose_tile(op, batch);
+    if (cfg < 0)
+        return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
+                    op.name.c_str(), op.M, op.cout / 8, op.Lout);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->profile) {
+        if (m->ev_used == m->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            m->ev_pool.push_back({a, b});
+        }
+        e0 = m->ev_pool[m->ev_used].first;
+        e1 = m->ev_pool[m->ev_used].second;
+        ++m->ev_used;
+        m->prof_flops += op.flops_per_sample * batch;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    int rc;
+    switch (cfg) {
+        case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, st); break;
+        case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, st); break;
+        case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, st); break;
+        default: rc = launch_conv_cfg<3>(p, op.taps, op.stride, st); break;
+    }
+    if (rc != DAD_OK) return rc;
+    if (m->profile) HIP_TRY(hipEventRecord(e1, st));
+    return DAD_OK;
+}
+
+int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    if (!m->finalized) return fail(DAD_E_STATE, "dad_model_finalize has not been called");
+    if (batch <= 0) return fail(DAD_E_INVALID, "batch must be positive (got %d)", batch);
+    if (t < 0 || t >= m->cfg.n_timesteps)
+        return fail(DAD_E_RANGE, "index %d is out of bounds for the schedule of size %d", t,
+                    m->cfg.n_timesteps);
+    const size_t need = (size_t)m->plan.floats_per_sample * batch * sizeof(float);
+    if (ws_bytes < need)
+        return fail(DAD_E_WORKSPACE, "workspace has %zu bytes, batch %d needs %zu", ws_bytes, batch,
+                    need);
+    return DAD_OK;
+}
+
+int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStream_t st) {
+    for (const ConvOp& op : m->plan.convs) {
+        const int rc = run_conv(m, op, x, ws, batch, t, st);
+        if (rc != DAD_OK) return rc;
+    }
+    return DAD_OK;
+}
+
+int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const dad_step_args* a,
+              int x_out_disabled, float* eps_only, float* ws, hipStream_t st) {
+    const dad_cfg& c = m->cfg;
+    dad::FinalParams p{};
+    p.act = ws + m->plan.bufs[m->plan.final_act].offset * (long)batch;
+    p.w = m->d_final_w; p.bias = m->d_final_b;
+    p.dim = c.dim; p.td = c.transition_dim; p.B = batch; p.H = c.horizon;
+    p.predict_epsilon = c.predict_epsilon; p.clip_denoised = c.clip_denoised;
+    if (eps_only) {
+        p.x = const_cast<float*>(x_ro);
+        p.eps_out = eps_only;
+        p.x_out_disabled = 1;
+    } else {
+        p.x = x;
+        p.noise = a->noise; p.cond0 = a->cond0; p.cond_per_row = a->cond_per_row;
+        p.guide = (a->guide_grad && a->guide_weight > 0.0f) ? a->guide_grad : nullptr;
+        p.mean_out = a->mean_out; p.eps_out = a->eps_out;
+        p.x_out_disabled = x_out_disabled;
+        const float lv = m->sched[4][t];
+        p.c_recip = m->sched[0][t]; p.c_recipm1 = m->sched[1][t];
+        p.coef1 = m->sched[2][t]; p.coef2 = m->sched[3][t];
+        p.sigma = t == 0 ? 0.0f : expf(0.5f * lv);
+        p.guide_scale = a->guide_weight * expf(lv);
+        p.seed = a->seed;
+        p.elem_offset = a->row_offset * (uint64_t)c.horizon * (uint64_t)c.transition_dim;
+        p.draw = a->draw;
+    }
+    constexpr int JB = 8;
+    const int td_pad = (c.transition_dim + JB - 1) / JB * JB;
+    const size_t lds = ((size_t)td_pad * c.dim + td_pad) * sizeof(float);
+    const long N = (long)batch * c.horizon;
+    const int threads = 256;
+    hipLaunchKernelGGL(dad::final_posterior_kernel<JB>, dim3((unsigned)((N + threads - 1) / threads)),
+                       dim3(threads), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return DAD_OK;
+}
+
+int run_project(const dad_project_args* pa, float alpha, float* x, int batch, int horizon,
+                hipStream_t st) {
+    if (!pa || !pa->P) return fail(DAD_E_INVALID, "projection arguments missing");
+    if (alpha <= 0.0f) return DAD_OK;                     // policies.py:428-429
+    {
+        const int rc0 = configure_kernels();
+        if (rc0 != DAD_OK) return rc0;
+    }
+    dad::ProjParams p{};
+    p.P = pa->P; p.obs_mean = pa->obs_mean; p.obs_std = pa->obs_std;
+    p.act_mean = pa->act_mean; p.act_std = pa->act_std;
+    p.x = x; p.B = batch; p.H = horizon; p.n = pa->state_dim; p.od = pa->observation_dim;
+    p.m = pa->action_dim;
+    p.D = (horizon + 1) * p.n + horizon * p.m;
+    p.alpha = alpha;
+    p.one_minus_alpha = (float)(1.0 - (double)alpha);
+    constexpr int RB = 4;
+    const size_t lds = (size_t)RB * p.D * sizeof(float);
+    if (lds > 160 * 1024) return fail(DAD_E_INVALID, "projection dimension D=%d too large", p.D);
+    hipLaunchKernelGGL(dad::project_kernel<RB>, dim3((batch + RB - 1) / RB), dim3(256), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return DAD_OK;
+}
+
+}  // namespace
+
+// ===================================================================================== ABI
+extern "C" {
+
+const char* dad_last_error(void) { return g_err; }
+const char* dad_version(void) { return "dad-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int dad_model_create(const dad_cfg* cfg, dad_model** out) {
+    if (!cfg || !out) return fail(DAD_E_INVALID, "null argument");
+    if (cfg->kernel_size != 5) return fail(DAD_E_INVALID, "kernel_size %d unsupported (5 only)", cfg->kernel_size);
+    if (cfg->n_levels < 1 || cfg->n_levels > DAD_MAX_LEVELS)
+        return fail(DAD_E_INVALID, "n_levels %d out of range", cfg->n_levels);
+    if (cfg->transition_dim < 1 || cfg->dim < 4 || (cfg->dim & 1) || cfg->time_dim < 1)
+        return fail(DAD_E_INVALID, "bad transition_dim/dim/time_dim");
+    if (!is_pow2(cfg->horizon) || (cfg->horizon >> (cfg->n_levels - 1)) < 4)
+        return fail(DAD_E_INVALID, "horizon %d must be a power of two with horizon / 2^(levels-1) >= 4",
+                    cfg->horizon);
+    if (cfg->n_timesteps < 1) return fail(DAD_E_INVALID, "n_timesteps must be positive");
+    for (int i = 0; i < cfg->n_levels; ++i) {
+        const int ch = cfg->channels[i];
+        if (ch < 32 || ch % 32 != 0 || !is_pow2(ch / 8))
+            return fail(DAD_E_INVALID, "level %d has %d channels: need a multiple of 32 with C/8 a power of two",
+                        i, ch);
+    }
+    if (cfg->dim % 32 != 0) return fail(DAD_E_INVALID, "dim %d must be a multiple of 32", cfg->dim);
+    std::unique_ptr<dad_model> m(new dad_model());
+    m->cfg = *cfg;
+    const int rc = build_plan(m.get());
+    if (rc != DAD_OK) return rc;
+    *out = m.release();
+    return DAD_OK;
+}
+
+void dad_model_destroy(dad_model* m) {
+    if (!m) return;
+    free_device(m);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    for (auto& e : m->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete m;
+}
+
+int dad_model_load_weight(dad_model* m, const char* key, const float* data, const int64_t* shape,
+                          int32_t ndim) {
+    if (!m || !key || !data || !shape) return fail(DAD_E_INVALID, "null argument");
+    auto it = m->expected.find(key);
+    if (it == m->expected.end()) return fail(DAD_E_KEY, "unexpected key '%s'", key);
+    if ((int)it->second.size() != ndim) return fail(DAD_E_KEY, "'%s': rank %d, expected %zu", key, ndim, it->second.size());
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] != it->second[i])
+            return fail(DAD_E_KEY, "'%s': size mismatch at dim %d (%lld vs %lld)", key, i,
+                        (long long)shape[i], (long long)it->second[i]);
+        n *= (size_t)shape[i];
+    }
+    HostTensor& t = m->raw[key];
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data, data + n);
+    m->finalized = false;
+    return DAD_OK;
+}
+
+int dad_model_load_schedule(dad_model* m, const float* a, const float* b, const float* c1,
+                            const float* c2, const float* lv) {
+    if (!m || !a || !b || !c1 || !c2 || !lv) return fail(DAD_E_INVALID, "null argument");
+    const float* src[5] = {a, b, c1, c2, lv};
+    for (int i = 0; i < 5; ++i) m->sched[i].assign(src[i], src[i] + m->cfg.n_timesteps);
+    m->have_sched = true;
+    return DAD_OK;
+}
+
+int dad_model_finalize(dad_model* m, dad_stream_t stream) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    if (!m->have_sched) return fail(DAD_E_STATE, "schedule not loaded");
+    for (auto& kv : m->expected)
+        if (!m->raw.count(kv.first)) return fail(DAD_E_KEY, "missing key '%s'", kv.first.c_str());
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    {
+        const int rc0 = configure_kernels();
+        if (rc0 != DAD_OK) return rc0;
+    }
+    free_device(m);
+    const dad_cfg& c = m->cfg;
+
+    for (ConvOp& op : m->plan.convs) {
+        const HostTensor& w = m->raw[op.name + ".weight"];
+        const HostTensor& b = m->raw[op.name + ".bias"];
+        std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad)
+                                                       : pack_conv(w, op.cin_pad, op.taps);
+        int rc = upload(m, packed, &op.d_w);
+        if (rc != DAD_OK) return rc;
+        std::vector<float> bias = b.data;
+        if (op.kind == CONV_UP) bias.insert(bias.end(), b.data.begin(), b.data.end());
+        if ((rc = upload(m, bias, &op.d_bias)) != DAD_OK) return rc;
+        if (!op.norm.empty()) {
+            if ((rc = upload(m, m->raw[op.norm + ".weight"].data, &op.d_gamma)) != DAD_OK) return rc;
+            if ((rc = upload(m, m->raw[op.norm + ".bias"].data, &op.d_beta)) != DAD_OK) return rc;
+        }
+    }
+    int rc;
+    if ((rc = upload(m, m->raw["final_conv.1.weight"].data, &m->d_final_w)) != DAD_OK) return rc;
+    if ((rc = upload(m, m->raw["final_conv.1.bias"].data, &m->d_final_b)) != DAD_OK) return rc;
+
+    // ---- time-embedding tables: every t in [0, T) at once --------------------------------
+    const int T = c.n_timesteps, dim = c.dim, tdm = c.time_dim;
+    std::vector<float> emb((size_t)T * dim);
+    {   // SinusoidalPosEmb (temporal_unet.py:27-31) in fp32, as torch computes it
+        const int half = dim / 2;
+        const float scale = (float)(-(std::log(10000.0) / (half - 1)));
+        for (int t = 0; t < T; ++t)
+            for (int j = 0; j < half; ++j) {
+                const float f = std::exp((float)j * scale);
+                const float arg = (float)t * f;
+                emb[(size_t)t * dim + j] = std::sin(arg);
+                emb[(size_t)t * dim + half + j] = std::cos(arg);
+            }
+    }
+    float *d_emb, *d_h1, *d_temb, *d_w, *d_b;
+    if ((rc = upload(m, emb, &d_emb)) != DAD_OK) return rc;
+    std::vector<float> zeros((size_t)T * 4 * tdm, 0.0f);
+    if ((rc = upload(m, zeros, &d_h1)) != DAD_OK) return rc;
+    zeros.resize((size_t)T * tdm);
+    if ((rc = upload(m, zeros, &d_temb)) != DAD_OK) return rc;
+    zeros.assign((size_t)T * std::max(1, m->plan.temb_width), 0.0f);
+    if ((rc = upload(m, zeros, &m->d_temb_table)) != DAD_OK) return rc;
+    auto linear = [&](const float* in, const std::string& key, float* out, int K, int M, int stride,
+                      int mish_in) -> int {
+        int r;
+        if ((r = upload(m, m->raw[key + ".weight"].data, &d_w)) != DAD_OK) return r;
+        if ((r = upload(m, m->raw[key + ".bias"].data, &d_b)) != DAD_OK) return r;
+        const long total = (long)T * M;
+        hipLaunchKernelGGL(dad::table_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                           0, st, in, d_w, d_b, out, T, K, M, stride, mish_in);
+        HIP_TRY(hipGetLastError());
+        return DAD_OK;
+    };
+    if ((rc = linear(d_emb, "time_mlp.1", d_h1, dim, 4 * tdm, 4 * tdm, 0)) != DAD_OK) return rc;
+    if ((rc = linear(d_h1, "time_mlp.3", d_temb, 4 * tdm, tdm, tdm, 1)) != DAD_OK) return rc;
+    for (const ConvOp& op : m->plan.convs) {
+        if (op.temb_off < 0) continue;
+        std::string base = op.name.substr(0, op.name.size() - std::strlen(".blocks.0.block.0"));
+        if ((rc = linear(d_temb, base + ".time_mlp.1", m->d_temb_table + op.temb_off, tdm, op.cout,
+                         m->plan.temb_width, 1)) != DAD_OK) return rc;
+    }
+    void* rng = nullptr;
+    HIP_TRY(hipMalloc(&rng, 64));
+    m->owned.push_back(rng);
+    m->d_rng = (uint64_t*)rng;
+    HIP_TRY(hipStreamSynchronize(st));
+    m->raw.clear();
+    m->finalized = true;
+    return DAD_OK;
+}
+
+int dad_workspace_bytes(const dad_model* m, int32_t batch, size_t* bytes) {
+    if (!m || !bytes || batch <= 0) return fail(DAD_E_INVALID, "bad argument");
+    *bytes = (size_t)m->plan.floats_per_sample * (size_t)batch * sizeof(float);
+    return DAD_OK;
+}
+
+int dad_unet_forward(dad_model* m, const float* x, int32_t t, float* out, int32_t batch,
+                     void* workspace, size_t workspace_bytes, dad_stream_t stream) {
+    int rc = check_ready(m, batch, t, workspace_bytes);
+    if (rc != DAD_OK) return rc;
+    if (!x || !out || !workspace) return fail(DAD_E_INVALID, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_unet(m, x, t, batch, (float*)workspace, st)) != DAD_OK) return rc;
+    return run_final(m, nullptr, x, t, batch, nullptr, 1, out, (float*)workspace, st);
+}
+
+int dad_denoise_step(dad_model* m, float* x, int32_t t, int32_t batch, const dad_step_args* args,
+                     int32_t x_out_disabled, void* workspace, size_t workspace_bytes,
+                     dad_stream_t stream) {
+    int rc = check_ready(m, batch, t, workspace_bytes);
+    if (rc != DAD_OK) return rc;
+    if (!x || !args || !workspace) return fail(DAD_E_INVALID, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_unet(m, x, t, batch, (float*)workspace, st)) != DAD_OK) return rc;
+    return run_final(m, x, nullptr, t, batch, args, x_out_disabled, nullptr, (float*)workspace, st);
+}
+
+int dad_project(const dad_project_args* p, float alpha, float* x, int32_t batch, int32_t horizon,
+                dad_stream_t stream) {
+    if (!x || batch <= 0 || horizon <= 0) return fail(DAD_E_INVALID, "bad argument");
+    return run_project(p, alpha, x, batch, horizon, (hipStream_t)stream);
+}
+
+int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
+                    const float* noise_stack, uint64_t seed, uint64_t row_offset,
+                    const float* cond0, int32_t cond_per_row, const dad_project_args* proj,
+                    const float* proj_alphas_host, int32_t use_graph, void* workspace,
+                    size_t workspace_bytes, dad_stream_t stream) {
+    if (n_steps < 1) return fail(DAD_E_INVALID, "n_steps must be positive");
+    int rc = check_ready(m, batch, n_steps - 1, workspace_bytes);
+    if (rc != DAD_OK) return rc;
+    if (!x || !workspace) return fail(DAD_E_INVALID, "null pointer");
+    if (proj && !proj_alphas_host) return fail(DAD_E_INVALID, "projection needs per-step alphas");
+    hipStream_t st = (hipStream_t)stream;
+    const long step_elems = (long)batch * m->cfg.horizon * m->cfg.transition_dim;
+
+    auto enqueue_all = [&](hipStream_t st) -> int {
+        for (int j = 0; j < n_steps; ++j) {
+            const int t = n_steps - 1 - j;
+            dad_step_args a{};
+            a.noise = noise_stack ? noise_stack + (long)j * step_elems : nullptr;
+            a.seed = seed; a.row_offset = row_offset; a.draw = (uint64_t)(j + 1);
+            a.cond0 = cond0; a.cond_per_row = cond_per_row;
+            int r = run_unet(m, x, t, batch, (float*)workspace, st);
+            if (r != DAD_OK) return r;
+            if ((r = run_final(m, x, nullptr, t, batch, &a, 0, nullptr, (float*)workspace, st)) != DAD_OK)
+                return r;
+            if (proj && (r = run_project(proj, proj_alphas_host[t], x, batch, m->cfg.horizon, st)) != DAD_OK)
+                return r;
+        }
+        return DAD_OK;
+    };
+
+    if (!use_graph || m->profile) return enqueue_all(st);
+
+    // Graph replay: the whole T-step loop is one hipGraph keyed by every frozen pointer.
+    // Philox seeds are frozen too, so graphs are only used with an injected noise stack or
+    // when the caller accepts a per-(seed) capture; the seed is part of nothing here —
+    // callers wanting fresh noise per call pass noise_stack they refill (dad_fill_normal).
+    if (!noise_stack)
+        return fail(DAD_E_INVALID, "use_graph requires a noise stack (refill it with dad_fill_normal)");
+    GraphKey key{};
+    key.x = x; key.noise = noise_stack; key.cond = cond0; key.ws = workspace;
+    key.P = proj ? proj->P : nullptr;
+    key.n_steps = n_steps; key.batch = batch; key.cond_per_row = cond_per_row;
+    auto it = m->graphs.find(key);
+    if (it == m->graphs.end()) {
+        // capture on a private stream: the caller's stream may be the null stream, which
+        // cannot be captured; nothing executes during capture.
+        if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+        rc = enqueue_all(m->cap_stream);
+        hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
+        if (rc != DAD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(DAD_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(DAD_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        it = m->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, st));
+    return DAD_OK;
+}
+
+int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, uint64_t row_offset,
+                    uint64_t draw, dad_stream_t stream) {
+    if (!x || batch <= 0 || row_elems <= 0) return fail(DAD_E_INVALID, "bad argument");
+    const long n = (long)batch * row_elems;
+    hipLaunchKernelGGL(dad::fill_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, n, row_offset * (uint64_t)row_elems, draw, seed);
+    HIP_TRY(hipGetLastError());
+    return DAD_OK;
+}
+
+int dad_profile_enable(dad_model* m, int32_t on) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    m->profile = on != 0;
+    m->ev_used = 0;
+    m->prof_flops = 0;
+    return DAD_OK;
+}
+
+int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    double ms = 0;
+    for (size_t i = 0; i < m->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(m->ev_pool[i].second));
+        float d = 0;
+        HIP_TRY(hipEventElapsedTime(&d, m->ev_pool[i].first, m->ev_pool[i].second));
+        ms += d;
+    }
+    if (conv_ms) *conv_ms = ms;
+    if (conv_launches) *conv_launches = (int64_t)m->ev_used;
+    if (conv_flops) *conv_flops = m->prof_flops;
+    m->ev_used = 0;
+    m->prof_flops = 0;
+    return DAD_OK;
+}
+
+}  // extern "C"

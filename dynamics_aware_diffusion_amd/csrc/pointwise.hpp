@@ -1,0 +1,223 @@
+// pointwise.hpp — the bandwidth-bound kernels around the conv GEMMs:
+//   * final 1x1 conv + reverse-diffusion posterior step in one pass
+//       (temporal_unet.py:196 final_conv[1]; diffusion.py:159-223; policies.py:84-110)
+//   * counter-based normal generator (Philox4x32-10 + Box-Muller) replacing torch.randn
+//   * dynamics projection gather -> x@P -> blend -> scatter (policies.py:409-485)
+//   * one-off time-embedding table builders (temporal_unet.py:19-32,97-100,155-160)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_gemm.hpp"
+
+namespace dad {
+
+// ------------------------------------------------------------------------------ Philox
+struct PhiloxKey { uint32_t k0, k1; };
+
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0;
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Standard normal for global element index `e` of draw `draw`:
+//   quad = e >> 2 picks the Philox block, e & 3 picks one of its four Box-Muller outputs.
+__device__ __forceinline__ float philox_normal(uint64_t e, uint64_t draw, uint64_t seed) {
+    uint32_t r[4];
+    const uint64_t q = e >> 2;
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)draw, (uint32_t)(draw >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const int pair = (int)((e >> 1) & 1);
+    const uint32_t ra = r[2 * pair], rb = r[2 * pair + 1];
+    const float u1 = ((float)(ra >> 9) + 0.5f) * (1.0f / 8388608.0f);   // (0,1), exact
+    const float u2 = (float)(rb >> 8) * (1.0f / 16777216.0f);            // [0,1), exact
+    const float rad = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.28318530717958647692f * u2;
+    return (e & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+
+__global__ void fill_normal_kernel(float* x, long n_elems, uint64_t elem_offset, uint64_t draw,
+                                   uint64_t seed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_elems) x[i] = philox_normal(elem_offset + (uint64_t)i, draw, seed);
+}
+
+// -------------------------------------------------------------- final conv + posterior
+struct FinalParams {
+    const float* act;        // CNL [dim][B*H]: output of final_conv[0]
+    const float* w;          // [td][dim] final_conv[1].weight (k=1)
+    const float* bias;       // [td]
+    float* x;                // (B,H,td) trajectory, updated in place unless x_out_disabled
+    const float* noise;      // (B,H,td) or nullptr -> Philox
+    const float* cond0;      // inpainting for horizon step 0 or nullptr
+    const float* guide;      // (B,H,td) guide gradient or nullptr
+    float* mean_out;         // optional
+    float* eps_out;          // optional
+    int32_t dim, td, B, H;
+    int32_t cond_per_row;
+    int32_t predict_epsilon, clip_denoised;
+    int32_t x_out_disabled;  // 1: only eps_out / mean_out are produced
+    float c_recip, c_recipm1, coef1, coef2;   // schedule scalars at t (diffusion.py:164-178)
+    float sigma;             // [t != 0] * exp(0.5 * log_var_t)
+    float guide_scale;       // guide_weight * exp(log_var_t)      (policies.py:97)
+    uint64_t seed, elem_offset, draw;
+};
+
+template <int JB>
+__global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams p) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];   // [td_pad][dim] + [td_pad]
+    const int td = p.td, dim = p.dim;
+    const int td_pad = (td + JB - 1) / JB * JB;
+    float* wl = ws;
+    float* bl = ws + td_pad * dim;
+    for (int i = threadIdx.x; i < td_pad * dim; i += blockDim.x)
+        wl[i] = (i < td * dim) ? p.w[i] : 0.0f;
+    for (int i = threadIdx.x; i < td_pad; i += blockDim.x) bl[i] = (i < td) ? p.bias[i] : 0.0f;
+    __syncthreads();
+
+    const long N = (long)p.B * p.H;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int b = (int)(n / p.H);
+    const int l = (int)(n - (long)b * p.H);
+    const float* col = p.act + n;
+
+    for (int j0 = 0; j0 < td; j0 += JB) {
+        float acc[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) acc[jj] = 0.0f;
+        for (int c = 0; c < dim; ++c) {
+            const float a = col[(long)c * N];
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) acc[jj] = fmaf(wl[(j0 + jj) * dim + c], a, acc[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = j0 + jj;
+            if (j >= td) break;
+            const long idx = n * td + j;
+            const float out = acc[jj] + bl[j];
+            if (p.eps_out != nullptr) p.eps_out[idx] = out;
+            if (p.x_out_disabled && p.mean_out == nullptr) continue;
+            const float xv = p.x[idx];
+            float x0 = p.predict_epsilon ? p.c_recip * xv - p.c_recipm1 * out : out;
+            if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            float mean = p.coef1 * x0 + p.coef2 * xv;
+            if (p.guide != nullptr) mean = mean + p.guide_scale * p.guide[idx];
+            if (p.mean_out != nullptr) p.mean_out[idx] = mean;
+            if (p.x_out_disabled) continue;
+            const float z = (p.noise != nullptr)
+                                ? p.noise[idx]
+                                : philox_normal(p.elem_offset + (uint64_t)idx, p.draw, p.seed);
+            float xn = mean + p.sigma * z;
+            if (l == 0 && p.cond0 != nullptr)
+                xn = p.cond0[(p.cond_per_row ? (long)b * td : 0) + j];
+            p.x[idx] = xn;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------- projection
+struct ProjParams {
+    const float* P;          // [D][D]
+    const float* obs_mean; const float* obs_std; const float* act_mean; const float* act_std;
+    float* x;                // (B,H,od+m) in place
+    int32_t B, H, n, od, m, D;
+    float alpha, one_minus_alpha;
+};
+
+template <int RB>
+__global__ __launch_bounds__(256) void project_kernel(const ProjParams p) {
+    extern __shared__ __attribute__((aligned(16))) float v[];    // [RB][D]
+    const int D = p.D, H = p.H, n = p.n, m = p.m, td = p.od + p.m;
+    const int b0 = blockIdx.x * RB;
+    const int nstate = (H + 1) * n;
+    // gather + de-normalise: [s_0..s_{H-1}, s_{H-1}, a_0..a_{H-1}]  (policies.py:434-448)
+    for (int e = threadIdx.x; e < RB * D; e += blockDim.x) {
+        const int r = e / D, d = e - r * D;
+        const int b = b0 + r;
+        float val = 0.0f;
+        if (b < p.B) {
+            const float* xb = p.x + (long)b * H * td;
+            if (d < nstate) {
+                const int ts = d / n, k = d - ts * n;
+                const int tsrc = ts < H ? ts : H - 1;
+                val = xb[tsrc * td + k] * p.obs_std[k] + p.obs_mean[k];
+            } else {
+                const int dd = d - nstate;
+                const int ts = dd / m, k = dd - ts * m;
+                val = xb[ts * td + p.od + k] * p.act_std[k] + p.act_mean[k];
+            }
+        }
+        v[e] = val;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.0f;
+        for (int k = 0; k < D; ++k) {
+            const float pk = p.P[(long)k * D + d];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = fmaf(v[r * D + k], pk, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int b = b0 + r;
+            if (b >= p.B) continue;
+            const float blended = p.alpha * acc[r] + p.one_minus_alpha * v[r * D + d];
+            float* xb = p.x + (long)b * H * td;
+            if (d < nstate) {
+                const int ts = d / n, k = d - ts * n;
+                if (ts < H) xb[ts * td + k] = (blended - p.obs_mean[k]) / p.obs_std[k];
+            } else {
+                const int dd = d - nstate;
+                const int ts = dd / m, k = dd - ts * m;
+                xb[ts * td + p.od + k] = (blended - p.act_mean[k]) / p.act_std[k];
+            }
+        }
+    }
+    // observation channels beyond the physical state are zero-padded (policies.py:475-480)
+    if (p.od > n) {
+        const int extra = p.od - n;
+        for (int e = threadIdx.x; e < RB * H * extra; e += blockDim.x) {
+            const int r = e / (H * extra);
+            const int rem = e - r * H * extra;
+            const int ts = rem / extra, k = rem - ts * extra;
+            const int b = b0 + r;
+            if (b < p.B) p.x[((long)b * H + ts) * td + n + k] = 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------- time-embedding tables
+// out[t][m] = b[m] + sum_k W[m][k] * f(in[t][k]),  f = Mish when mish_in (the reference's
+// nn.Sequential(Mish, Linear) / Linear -> Mish -> Linear chains), one thread per output.
+__global__ void table_linear_kernel(const float* in, const float* W, const float* b, float* out,
+                                    int T, int K, int M, int out_stride, int mish_in) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)T * M) return;
+    const int t = (int)(i / M), m = (int)(i - (long)t * M);
+    const float* x = in + (long)t * K;
+    const float* w = W + (long)m * K;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float v = mish_in ? mish_f32(x[k]) : x[k];
+        acc = fmaf(w[k], v, acc);
+    }
+    out[(long)t * out_stride + m] = acc + b[m];
+}
+
+}  // namespace dad

@@ -1,0 +1,151 @@
+"""``TemporalUnet`` — API mirror of ``m_diffuser.models.temporal_unet.TemporalUnet``
+(/root/reference/m_diffuser/models/temporal_unet.py:125-241) whose forward pass runs on the
+hand-written HIP engine (``csrc/``) instead of ``torch.nn`` layers.
+
+The module owns ordinary ``nn.Parameter`` tensors under exactly the reference's
+``state_dict`` keys, so ``load_state_dict`` of a reference
+checkpoint works unchanged; the engine keeps its own packed copy, refreshed whenever the
+parameters change.  There is no CPU forward: calling it with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .._engine import HipEngine
+from ..utils.synth import unet_param_shapes
+
+
+class _Node(nn.Module):
+    """Empty container; only exists so parameter paths spell the reference's keys."""
+
+
+def _attach(root: nn.Module, dotted: str, value: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    node = root
+    for name in parts[:-1]:
+        child = node._modules.get(name)
+        if child is None:
+            child = _Node()
+            node.add_module(name, child)
+        node = child
+    node.register_parameter(parts[-1], value)
+
+
+def _default_init(key: str, shape: Tuple[int, ...], fan_in: Dict[str, int]) -> torch.Tensor:
+    """PyTorch's default layer initialisation (kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+    for conv/linear weights and biases; GroupNorm affine = 1 / 0)."""
+    if ".block.1." in key:
+        return torch.ones(shape) if key.endswith("weight") else torch.zeros(shape)
+    stem = key.rsplit(".", 1)[0]
+    if key.endswith("weight"):
+        if len(shape) == 3:
+            fan = shape[1] * shape[2]
+            if key.endswith(".2.conv.weight") and shape[2] == 4:     # ConvTranspose1d (in,out,k)
+                fan = shape[1] * shape[2]
+        else:
+            fan = shape[1]
+        fan_in[stem] = fan
+    bound = 1.0 / math.sqrt(fan_in[stem])
+    return torch.empty(shape).uniform_(-bound, bound)
+
+
+class TemporalUnet(nn.Module):
+    """1-D conv U-Net denoiser eps_theta(x_t, t) on the MI355X HIP engine.
+
+    Same constructor as the reference (temporal_unet.py:135-140).  ``forward(x, time)`` takes
+    ``x`` (batch, horizon, transition_dim) and ``time`` (batch,) and returns a tensor like
+    ``x``; all rows must share one timestep, which is what every sampling call site does
+    (diffusion.py:248; guides/policies.py:146).
+    """
+
+    def __init__(self, transition_dim: int, dim: int = 128,
+                 dim_mults: Sequence[int] = (1, 2, 4, 8), kernel_size: int = 5,
+                 time_dim: Optional[int] = None):
+        super().__init__()
+        self.transition_dim = int(transition_dim)
+        self.dim = int(dim)
+        self.dim_mults = tuple(int(m) for m in dim_mults)
+        self.kernel_size = int(kernel_size)
+        self.time_dim = int(time_dim or dim)
+        self.channels = [self.dim * m for m in self.dim_mults]
+        fan: Dict[str, int] = {}
+        for key, shape in unet_param_shapes(self.transition_dim, self.dim, self.dim_mults,
+                                            self.kernel_size, self.time_dim).items():
+            _attach(self, key, nn.Parameter(_default_init(key, shape, fan)))
+        # engine state (not part of state_dict)
+        self._engine: Optional[HipEngine] = None
+        self._engine_sig = None
+        self._schedule: Optional[Dict[str, torch.Tensor]] = None
+        self._diffusion_opts = {"n_timesteps": 1000, "predict_epsilon": True,
+                                "clip_denoised": True}
+
+    # ------------------------------------------------------------------ engine plumbing
+    def bind_diffusion(self, schedule: Dict[str, torch.Tensor], n_timesteps: int,
+                       predict_epsilon: bool, clip_denoised: bool) -> None:
+        """Called by ``GaussianDiffusion``: hands over the schedule scalars the fused
+        posterior kernel needs (diffusion.py:117-128)."""
+        self._schedule = schedule
+        self._diffusion_opts = {"n_timesteps": int(n_timesteps),
+                                "predict_epsilon": bool(predict_epsilon),
+                                "clip_denoised": bool(clip_denoised)}
+
+    def _signature(self, horizon: int, device: torch.device):
+        params = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        opts = tuple(sorted(self._diffusion_opts.items()))
+        sched = None
+        if self._schedule is not None:
+            sched = tuple((k, v.data_ptr(), v._version) for k, v in sorted(self._schedule.items()))
+        return (horizon, str(device), opts, params, sched)
+
+    def engine(self, horizon: int, device: torch.device) -> HipEngine:
+        """Return the engine for (horizon, device), (re)building it if weights, schedule or
+        options changed since the last call."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                "TemporalUnet runs on the HIP engine only: move the model and its inputs to a "
+                f"ROCm device (got {device}); there is no CPU fallback")
+        sig = self._signature(horizon, device)
+        if self._engine is not None and sig == self._engine_sig:
+            return self._engine
+        opts = self._diffusion_opts
+        T = opts["n_timesteps"]
+        eng = HipEngine(transition_dim=self.transition_dim, dim=self.dim, channels=self.channels,
+                        horizon=horizon, n_timesteps=T, time_dim=self.time_dim,
+                        kernel_size=self.kernel_size, predict_epsilon=opts["predict_epsilon"],
+                        clip_denoised=opts["clip_denoised"], device=device)
+        if self._schedule is not None:
+            sched = self._schedule
+        else:
+            zero = torch.zeros(T)
+            sched = {k: zero for k in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                                       "posterior_mean_coef1", "posterior_mean_coef2",
+                                       "posterior_log_variance_clipped")}
+        eng.load(dict(self.named_parameters()), sched)
+        self._engine, self._engine_sig = eng, sig
+        return eng
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def shared_timestep(time: Union[int, torch.Tensor]) -> int:
+        if isinstance(time, int):
+            return time
+        lo, hi = int(time.min()), int(time.max())
+        if lo != hi:
+            raise NotImplementedError(
+                "the HIP sampler evaluates one timestep per call (all rows share t, as in "
+                "p_sample_loop / sample_loop); got timesteps in [%d, %d]" % (lo, hi))
+        return lo
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, time: Union[int, torch.Tensor]) -> torch.Tensor:
+        t = self.shared_timestep(time)
+        if t >= self._diffusion_opts["n_timesteps"] and self._schedule is None:
+            # bare denoiser: grow the time table on demand
+            self._diffusion_opts["n_timesteps"] = max(2 * self._diffusion_opts["n_timesteps"], t + 1)
+        eng = self.engine(int(x.shape[1]), x.device)
+        return eng.unet_forward(x.contiguous().float(), t)

@@ -1,0 +1,161 @@
+/*
+ * dad.h — C ABI of libdad_hip.so: the MI355X (gfx950) reverse-diffusion planning sampler.
+ *
+ * The reference (darshangm/dynamics-aware-diffusion) is 100 % Python and has no FFI seam;
+ * its seam is the Python class API of m_diffuser.models / m_diffuser.guides that
+ * scripts/evaluate.py consumes.  This library sits UNDER a Python
+ * mirror of that API (dynamics_aware_diffusion_amd/) and is bound with ctypes.  Each entry
+ * point names the reference function it replaces (paths under /root/reference/).
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 on success or a negative DAD_E_* code;
+ *    dad_last_error() returns a thread-local message.  Nothing throws or aborts.
+ *  - device pointers are fp32, contiguous, owned by the caller (torch-ROCm tensors);
+ *    trajectories use the reference's external layout (batch, horizon, transition_dim).
+ *  - all work is enqueued asynchronously on the caller's hipStream_t (passed as void*);
+ *    step functions never allocate: the caller passes a workspace of dad_workspace_bytes().
+ *  - one dad_model per device per process; functions are thread-compatible, not thread-safe.
+ */
+#ifndef DAD_H
+#define DAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAD_OK 0
+#define DAD_E_INVALID (-1)   /* bad argument / unsupported shape                      */
+#define DAD_E_STATE (-2)     /* call order violated (e.g. step before finalize)       */
+#define DAD_E_KEY (-3)       /* unknown or duplicate weight key, or shape mismatch    */
+#define DAD_E_HIP (-4)       /* a HIP runtime call failed (message has hipGetErrorString) */
+#define DAD_E_RANGE (-5)     /* timestep outside the loaded schedule (reference: RuntimeError
+                                from gather, m_diffuser/models/diffusion.py:28)       */
+#define DAD_E_WORKSPACE (-6) /* workspace too small                                   */
+
+#define DAD_MAX_LEVELS 8
+
+typedef struct dad_model dad_model;
+typedef void* dad_stream_t; /* hipStream_t */
+
+/* Architecture of the denoiser + diffusion constants.
+ * Mirrors TemporalUnet.__init__ (m_diffuser/models/temporal_unet.py:135-197) and
+ * GaussianDiffusion.__init__ (m_diffuser/models/diffusion.py:62-94). */
+typedef struct dad_cfg {
+    int32_t transition_dim;           /* observation_dim + action_dim                     */
+    int32_t dim;                      /* width of the sinusoidal embedding                */
+    int32_t time_dim;                 /* time-embedding width (reference: == dim)         */
+    int32_t n_levels;                 /* len(dim_mults)                                   */
+    int32_t channels[DAD_MAX_LEVELS]; /* dim * dim_mults[i] per level                     */
+    int32_t kernel_size;              /* 5 (only value supported)                         */
+    int32_t horizon;                  /* planning horizon H; H / 2^(n_levels-1) >= 1      */
+    int32_t n_timesteps;              /* length T of the trained schedule                 */
+    int32_t predict_epsilon;          /* diffusion.py:192-197                             */
+    int32_t clip_denoised;            /* diffusion.py:199-200                             */
+} dad_cfg;
+
+const char* dad_last_error(void);
+const char* dad_version(void);
+
+/* Replaces: TemporalUnet(...) / GaussianDiffusion(...) construction + .to(device). */
+int dad_model_create(const dad_cfg* cfg, dad_model** out);
+void dad_model_destroy(dad_model* m);
+
+/* Replaces: load_state_dict (scripts/evaluate.py:198).  `key` is the reference's
+ * state_dict key WITHOUT the leading "model." (SURVEY.md Appendix C); `data` is a HOST
+ * fp32 pointer in the reference's layout; the library packs and uploads its own copy.
+ * May be called again for the same key before the next finalize (weights updated). */
+int dad_model_load_weight(dad_model* m, const char* key, const float* data,
+                          const int64_t* shape, int32_t ndim);
+
+/* The five schedule buffers the reverse step reads (diffusion.py:117-128), HOST fp32,
+ * each of length cfg.n_timesteps: sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped. */
+int dad_model_load_schedule(dad_model* m, const float* sqrt_recip, const float* sqrt_recipm1,
+                            const float* coef1, const float* coef2, const float* log_var);
+
+/* Checks every tensor is present, builds the per-timestep time-embedding tables
+ * (SinusoidalPosEmb + time_mlp + every block's Mish->Linear, temporal_unet.py:19-32,
+ * 97-100,155-160 — batch-invariant during sampling) and the launch plan. */
+int dad_model_finalize(dad_model* m, dad_stream_t stream);
+
+/* Bytes of device scratch one call at batch size B needs (activations only). */
+int dad_workspace_bytes(const dad_model* m, int32_t batch, size_t* bytes);
+
+/* Replaces: TemporalUnet.forward(x, t) with one shared timestep t
+ * (temporal_unet.py:199-241).  x, out: (B, H, td) device fp32.  out = eps_theta(x, t). */
+int dad_unet_forward(dad_model* m, const float* x, int32_t t, float* out, int32_t batch,
+                     void* workspace, size_t workspace_bytes, dad_stream_t stream);
+
+/* Arguments of one reverse step beyond (x, t). All pointers may be NULL unless noted. */
+typedef struct dad_step_args {
+    const float* noise;      /* (B,H,td) injected z; NULL => in-kernel Philox            */
+    uint64_t seed;           /* Philox key (used when noise == NULL)                     */
+    uint64_t row_offset;     /* global index of batch row 0 (multi-GPU shards)           */
+    uint64_t draw;           /* Philox draw id of this step (loop uses T - t)            */
+    const float* cond0;      /* inpainting value for horizon step 0: (td) or (B,td)      */
+    int32_t cond_per_row;    /* 0: cond0 is (td) broadcast; 1: (B,td)                    */
+    const float* guide_grad; /* (B,H,td) d guide/d x_t, or NULL                          */
+    float guide_weight;      /* policies.py:97                                           */
+    float* mean_out;         /* optional (B,H,td): posterior mean incl. guidance         */
+    float* eps_out;          /* optional (B,H,td): raw model output                      */
+} dad_step_args;
+
+/* Replaces: GaussianDiffusion.p_sample (diffusion.py:205-223) and
+ * GuidedPolicy.p_sample_with_guidance (guides/policies.py:65-112): U-Net, x0 prediction,
+ * clamp, posterior mean, guidance nudge, noise, inpainting — x updated IN PLACE.
+ * With args->mean_out set and x_out_disabled != 0 it is p_mean_variance only
+ * (diffusion.py:182-203) and x is left untouched. */
+int dad_denoise_step(dad_model* m, float* x, int32_t t, int32_t batch, const dad_step_args* args,
+                     int32_t x_out_disabled, void* workspace, size_t workspace_bytes,
+                     dad_stream_t stream);
+
+/* Replaces: GaussianDiffusion.p_sample_loop (diffusion.py:225-251) and
+ * GuidedPolicy.sample_loop without a guide (guides/policies.py:114-149): runs
+ * t = n_steps-1 .. 0 on x (which must already hold x_T, with conditions applied).
+ * noise_stack: (n_steps,B,H,td) injected z in loop order, or NULL for in-kernel Philox
+ * (draw id of iteration j is j+1; draw 0 is reserved for x_T, see dad_fill_normal).
+ * proj: optional projection applied after every step (README semantics; the shipped
+ * reference never calls it — SURVEY.md F5), alphas[n_steps] indexed by t on the HOST.
+ * use_graph != 0 replays a cached hipGraph of the whole loop (pointers must be stable). */
+typedef struct dad_project_args {
+    const float* P;         /* (D,D) device, D = (H+1)*n + H*m, row-major             */
+    const float* obs_mean;  /* device (od) */
+    const float* obs_std;
+    const float* act_mean;  /* device (ad) */
+    const float* act_std;
+    int32_t state_dim;      /* n */
+    int32_t observation_dim;/* od (== n in every reachable reference configuration)  */
+    int32_t action_dim;     /* m */
+} dad_project_args;
+
+int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
+                    const float* noise_stack, uint64_t seed, uint64_t row_offset,
+                    const float* cond0, int32_t cond_per_row,
+                    const dad_project_args* proj, const float* proj_alphas_host,
+                    int32_t use_graph, void* workspace, size_t workspace_bytes,
+                    dad_stream_t stream);
+
+/* Replaces: DynamicsAwarePolicy.apply_projection (guides/policies.py:409-485) for one
+ * alpha (policies.py:358-383 is evaluated by the caller).  x: (B,H,od+m) IN PLACE. */
+int dad_project(const dad_project_args* p, float alpha, float* x, int32_t batch,
+                int32_t horizon, dad_stream_t stream);
+
+/* Replaces: torch.randn(shape) for x_T (diffusion.py:241; policies.py:134) with the
+ * library's counter-based generator: element e of global row r gets Philox4x32-10
+ * (key = seed, counter = (draw, r*H*td + e)) -> Box-Muller.  Result is independent of how
+ * rows are sharded over GPUs. */
+int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed,
+                    uint64_t row_offset, uint64_t draw, dad_stream_t stream);
+
+/* Optional per-kernel timing: when enabled every conv-GEMM launch is bracketed by HIP
+ * events on the launch stream; dad_profile_read synchronises, sums and resets them. */
+int dad_profile_enable(dad_model* m, int32_t on);
+int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAD_H */

@@ -1,0 +1,311 @@
+"""GPU parity: the HIP path (through the Python mirror -> ctypes -> C ABI) against the golden
+vectors of the real reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32, stated per SURVEY.md §8(c)): the reference's own fp32-vs-fp64 distance is
+~1.1e-6 for one U-Net forward and ~1.6e-6 for a full loop.  Gates:
+    single forward / single step  <= 2e-5 abs
+    full loop (T <= 100)          <= 1e-4 abs
+and "HIP is no farther from the fp64 truth than 4x the fp32 reference is (+1e-6)".
+"""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.util import as_torch, golden, max_abs
+
+pytestmark = pytest.mark.gpu
+
+TOL_STEP = 2e-5
+TOL_LOOP = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+_MODELS = {}
+
+
+def build(net: str, T: int, schedule: str, dev):
+    """GaussianDiffusion mirror with the synthetic weights of `net`, on the device."""
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    key = (net, T, schedule)
+    if key in _MODELS:
+        return _MODELS[key]
+    od, ad, td, dim, mults = cases.net_dims(net)
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    sd = {k: torch.from_numpy(v) for k, v in cases.net_weights(net).items()}
+    missing, unexpected = unet.load_state_dict(sd, strict=True)
+    diff = GaussianDiffusion(unet, cases.H, od, ad, n_timesteps=T, beta_schedule=schedule).to(dev)
+    if len(_MODELS) > 3:
+        _MODELS.clear()
+    _MODELS[key] = diff
+    return diff
+
+
+@contextlib.contextmanager
+def injected_noise(stack, dev):
+    """Serve stack[0], stack[1], ... to successive torch.randn / randn_like calls (same
+    harness as tests/golden/make_golden.py uses on the reference)."""
+    it = iter(torch.from_numpy(np.ascontiguousarray(stack)).to(dev))
+    real_randn, real_like = torch.randn, torch.randn_like
+
+    def fake_randn(*shape, out=None, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        z = next(it)
+        assert tuple(z.shape) == tuple(shape), (z.shape, shape)
+        if out is not None:
+            out.copy_(z)
+            return out
+        return z.clone()
+
+    def fake_like(x, **kw):
+        z = next(it)
+        assert z.shape == x.shape
+        return z.clone()
+
+    torch.randn, torch.randn_like = fake_randn, fake_like
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+
+
+def eps_gain(diff, t: int) -> float:
+    """|d mean / d eps| at step t = coef1_t * sqrt(1/abar_t - 1) (diffusion.py:163-178).
+
+    An error e in the model output moves the (unclamped) posterior mean by gain*e.  The gain is
+    ~100 at t = T-1 of the cosine schedule (beta clipped to 0.9999 => 1/sqrt(1-beta) = 100) and
+    <= 1 a few steps later, so single-step tolerances are stated on eps and scaled by it; the
+    reference's own fp32 rounding is amplified identically."""
+    g = float(diff.posterior_mean_coef1[t] * diff.sqrt_recipm1_alphas_cumprod[t])
+    return max(1.0, g)
+
+
+def test_library_loaded_and_versioned():
+    from dynamics_aware_diffusion_amd import _engine
+    lib = _engine.load_library()
+    assert b"gfx950" in lib.dad_version()
+
+
+@pytest.mark.parametrize("case", cases.FORWARD_CASES, ids=lambda c: c[0])
+def test_unet_forward_vs_reference(case, dev):
+    name, net, B, t = case
+    g = golden(name)
+    diff = build(net, cases.NETS[net][4], "cosine", dev)
+    x = torch.from_numpy(cases.forward_input(name, net, B)).to(dev)
+    eps = diff.model(x, torch.full((B,), t, device=dev, dtype=torch.long))
+    torch.cuda.synchronize()
+    got = eps.cpu().numpy()
+    assert got.shape == g["eps"].shape
+    err32 = max_abs(got, g["eps"])
+    err64 = max_abs(got, g["eps_fp64"])
+    ref64 = max_abs(g["eps"], g["eps_fp64"])
+    print(f"{name}: |hip-ref32|={err32:.2e} |hip-fp64|={err64:.2e} |ref32-fp64|={ref64:.2e}")
+    assert err32 <= TOL_STEP
+    assert err64 <= 4 * ref64 + 1e-6
+
+
+@pytest.mark.parametrize("case", cases.LOOP_CASES, ids=lambda c: c[0])
+def test_sampling_loops_vs_reference(case, dev):
+    name, net, T, n_steps, B, conditioned, schedule = case
+    g = golden(name)
+    diff = build(net, T, schedule, dev)
+    diff.n_timesteps = n_steps                       # evaluate.py:350-353
+    try:
+        noise = cases.loop_noise(name, net, n_steps, B)
+        x0 = torch.from_numpy(noise[0]).to(dev)
+        t = torch.full((B,), n_steps - 1, device=dev, dtype=torch.long)
+        if conditioned:
+            from dynamics_aware_diffusion_amd import GuidedPolicy
+            pol = GuidedPolicy(diff, normalizer=None)
+            cond = {0: torch.from_numpy(cases.loop_condition(name, net)).to(dev)}
+            with injected_noise(noise, dev):
+                x = pol.sample_loop(batch_size=B, conditions=cond)
+            x0[:, 0] = cond[0]
+            with injected_noise(noise[1:2], dev):
+                step = pol.p_sample_with_guidance(x0.clone(), t, cond)
+        else:
+            with injected_noise(noise, dev):
+                x = diff.p_sample_loop((B, cases.H, diff.transition_dim))
+            with injected_noise(noise[1:2], dev):
+                step = diff.p_sample(x0.clone(), t)
+        mean, logvar = diff.p_mean_variance(x0.clone(), t)
+        torch.cuda.synchronize()
+        e_mean = max_abs(mean.cpu().numpy(), g["first_mean"])
+        e_step = max_abs(step.cpu().numpy(), g["first_step"])
+        e_loop = max_abs(x.cpu().numpy(), g["x_final"])
+        print(f"{name}: mean {e_mean:.2e} step {e_step:.2e} loop {e_loop:.2e}")
+        assert tuple(logvar.shape) == (B, 1, 1)
+        assert np.array_equal(logvar.cpu().numpy(), g["first_logvar"])
+        tol = TOL_STEP * eps_gain(diff, n_steps - 1)
+        assert e_mean <= tol and e_step <= tol, (e_mean, e_step, tol)
+        assert e_loop <= TOL_LOOP
+        if conditioned:     # inpainted step 0 is exact
+            assert np.array_equal(x[:, 0].cpu().numpy(),
+                                  np.broadcast_to(cases.loop_condition(name, net), (B, diff.transition_dim)))
+    finally:
+        diff.n_timesteps = T
+
+
+def test_graph_replay_matches_eager(dev):
+    name, net, T, n_steps, B, conditioned, schedule = cases.LOOP_CASES[1]
+    diff = build(net, T, schedule, dev)
+    noise = cases.loop_noise(name, net, n_steps, B)
+    eng = diff._engine(dev)
+    stack = torch.from_numpy(noise[1:]).to(dev).contiguous()
+    cond = torch.from_numpy(cases.loop_condition(name, net)).to(dev)
+    outs = []
+    for use_graph in (False, True, True):
+        x = torch.from_numpy(noise[0]).to(dev).clone()
+        x[:, 0] = cond
+        if use_graph and len(outs) == 1:
+            xg = x                                   # graph freezes this pointer
+        if use_graph:
+            xg.copy_(x)
+            eng.sample_loop(xg, n_steps, noise_stack=stack, cond0=cond, use_graph=True)
+            torch.cuda.synchronize()
+            outs.append(xg.cpu().numpy().copy())
+        else:
+            eng.sample_loop(x, n_steps, noise_stack=stack, cond0=cond)
+            torch.cuda.synchronize()
+            outs.append(x.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+
+
+def synth_normal(shape):
+    from dynamics_aware_diffusion_amd.utils import synth
+    return synth.normal_like(77, "ragged", shape)
+
+
+def _value_model(od_dim, dev):
+    vw = {k: v.to(dev) for k, v in as_torch(cases.value_net_weights(od_dim)).items()}
+    F = torch.nn.functional
+
+    class V(torch.nn.Module):
+        def forward(self, obs):
+            return F.linear(torch.tanh(F.linear(obs, vw["w1"], vw["b1"])), vw["w2"], vw["b2"])
+    return V()
+
+
+@pytest.mark.parametrize("case", cases.GUIDE_CASES, ids=lambda c: c[0])
+def test_value_guidance_vs_reference(case, dev):
+    from dynamics_aware_diffusion_amd import ValueGuidedPolicy
+    name, net, T, B, gw = case
+    g = golden(name)
+    diff = build(net, T, "cosine", dev)
+    pol = ValueGuidedPolicy(diff, None, _value_model(diff.observation_dim, dev), guide_weight=gw)
+    noise = cases.loop_noise(name, net, T, B)
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net)).to(dev)}
+    with injected_noise(noise, dev):
+        x = pol.sample_loop(batch_size=B, conditions=cond)
+    x0 = torch.from_numpy(noise[0]).to(dev)
+    x0[:, 0] = cond[0]
+    t = torch.full((B,), T - 1, device=dev, dtype=torch.long)
+    with injected_noise(noise[1:2], dev):
+        step = pol.p_sample_with_guidance(x0.clone(), t, cond)
+    torch.cuda.synchronize()
+    assert max_abs(step.cpu().numpy(), g["first_step"]) <= TOL_STEP * eps_gain(diff, T - 1)
+    assert max_abs(x.cpu().numpy(), g["x_final"]) <= TOL_LOOP
+
+
+def test_projection_vs_reference(dev):
+    from dynamics_aware_diffusion_amd import DynamicsAwarePolicy
+    from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder
+    from oracle.projection import double_integrator
+    g = golden("projection")
+    for case, dt, Hh in cases.PROJ_MATRIX_CASES:
+        A, B = double_integrator(dt)
+        P = ProjectionMatrixBuilder(A, B, 4, 2).get_projection_matrix(Hh)
+        assert max_abs(P.numpy(), g[case]) <= 1e-6
+    A, B = double_integrator(0.1)
+    builder = ProjectionMatrixBuilder(A, B, 4, 2)
+    P = builder.get_projection_matrix(cases.H)
+    assert builder.verify_projection(P)
+    diff = build("tiny", 100, "cosine", dev)
+    norm = cases.NormalizerStub(4, 2)
+    for sched in cases.PROJ_SCHEDULES:
+        pol = DynamicsAwarePolicy(diff, projection_matrix=P, normalizer=norm, state_dim=4,
+                                  observation_dim=4, action_dim=2, horizon=cases.H,
+                                  projection_schedule=sched, projection_strength=cases.PROJ_STRENGTH)
+        for t in cases.PROJ_T:
+            assert abs(pol._get_projection_alpha(t) - float(g[f"alpha_{sched}_{t}"])) <= 1e-12
+            x = torch.from_numpy(cases.projection_input(f"proj_{sched}_{t}")).to(dev)
+            keep = x.clone()
+            y = pol.apply_projection(x, t)
+            torch.cuda.synchronize()
+            assert torch.equal(x, keep)                          # input untouched
+            err = max_abs(y.cpu().numpy(), g[f"apply_{sched}_{t}"])
+            assert err <= 5e-6, (sched, t, err)
+    # ragged batch (257 = 64 blocks of 4 + 1) against the oracle on the same input
+    from oracle import projection as op
+    pol = DynamicsAwarePolicy(diff, projection_matrix=P, normalizer=norm, state_dim=4,
+                              observation_dim=4, action_dim=2, horizon=cases.H,
+                              projection_schedule="constant", projection_strength=1.0)
+    xs = synth_normal((257, cases.H, 6))
+    y = pol.apply_projection(torch.from_numpy(xs).to(dev), 0)
+    stats = [torch.from_numpy(v) for v in (norm.obs_mean, norm.obs_std, norm.action_mean, norm.action_std)]
+    want = op.apply_projection(torch.from_numpy(xs), P, 1.0, 4, 4, *stats)
+    assert max_abs(y.cpu().numpy(), want.numpy()) <= 5e-6
+    # error parity: observation_dim != state_dim raises like the reference's broadcast
+    bad = DynamicsAwarePolicy(diff, projection_matrix=P, normalizer=cases.NormalizerStub(6, 2),
+                              state_dim=4, observation_dim=6, action_dim=2, horizon=cases.H)
+    with pytest.raises(RuntimeError):
+        bad.apply_projection(torch.zeros(2, cases.H, 8, device=dev), 0)
+    with pytest.raises(ValueError):
+        DynamicsAwarePolicy(diff, projection_matrix=P, normalizer=norm, horizon=cases.H,
+                            projection_schedule="cubic")._get_projection_alpha(0)
+
+
+def test_get_action_glue_vs_reference(dev):
+    from dynamics_aware_diffusion_amd import GuidedPolicy
+    from dynamics_aware_diffusion_amd.utils import synth
+    g = golden("glue")
+    diff = build("tiny", 20, "cosine", dev)
+    norm = cases.NormalizerStub(4, 2)
+    obs = cases.glue_observations()
+    for ah in cases.ACTION_HORIZONS:
+        pol = GuidedPolicy(diff, norm, action_horizon=ah)
+        acts, sizes, plans = [], [], 0
+        for i in range(cases.N_GET_ACTION_CALLS):
+            if len(pol.action_buffer) == 0:
+                stack = synth.normal_like(52, f"glue.ah{ah}.plan{plans}", (21, 1, cases.H, 6))
+                plans += 1
+                with injected_noise(stack, dev):
+                    a = pol.get_action(obs[i])
+            else:
+                a = pol.get_action(obs[i])
+            acts.append(a)
+            sizes.append(len(pol.action_buffer))
+        assert plans == int(g[f"plans_ah{ah}"])
+        assert np.array_equal(np.array(sizes), g[f"buffer_ah{ah}"])
+        assert max_abs(np.stack(acts), g[f"actions_ah{ah}"]) <= TOL_LOOP
+
+
+def test_out_of_schedule_timestep_raises(dev):
+    """sampling more steps than the trained schedule is a RuntimeError."""
+    diff = build("tiny", 20, "cosine", dev)
+    diff.n_timesteps = 25
+    try:
+        with pytest.raises(RuntimeError):
+            diff.p_sample_loop((1, cases.H, 6))
+        with pytest.raises(RuntimeError):
+            diff.p_mean_variance(torch.zeros(1, cases.H, 6, device=dev),
+                                 torch.full((1,), 25, device=dev, dtype=torch.long))
+    finally:
+        diff.n_timesteps = 20
+
+
+def test_cpu_tensors_are_refused():
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    unet = TemporalUnet(6, dim=32, dim_mults=(1, 2))
+    with pytest.raises(RuntimeError):
+        unet(torch.zeros(1, 32, 6), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        GaussianDiffusion(unet, 32, 4, 2, n_timesteps=10).p_sample_loop((1, 32, 6))
