@@ -56,6 +56,7 @@ struct ConvOp {
     int Lin, Lout;           // GEMM per-sample lengths (CONV_UP: Lout == Lin, stores 2*Lin)
     int src0, src1, dst, res;
     int temb_off;            // offset into the per-t table, or -1
+    int kc = 16;             // K chunk the weights are packed for (8 when C_out/8 == 256)
     // device tensors (owned by the model)
     float* d_w = nullptr;
     float* d_bias = nullptr;
@@ -77,13 +78,17 @@ struct Plan {
     int temb_width = 0;       // sum of C_out over residual blocks
 };
 
-struct TileCfg { int BM, BN, WM, WN, KC; };
+struct TileCfg { int BM, BN, SK, KC; };
+// Block tile (BM channels x BN positions), SK-way intra-block split-K, K chunk.  Every
+// configuration runs 8 waves per block except the last (4 waves, two blocks per CU).
 const TileCfg kTiles[] = {
-    {32, 64, 1, 2, 16},    // 0
-    {64, 64, 2, 2, 16},    // 1
-    {128, 64, 4, 2, 8},    // 2
-    {256, 64, 4, 2, 8},    // 3
+    {32, 64, 4, 32},    // 0: few output tiles -> deepest split-K
+    {64, 64, 2, 16},    // 1: the workhorse at batch 256
+    {128, 64, 1, 16},   // 2: GroupNorm groups of 128 channels / plentiful tiles
+    {256, 32, 1, 8},    // 3: GroupNorm groups of 256 channels (C = 2048)
+    {64, 64, 1, 16},    // 4: plentiful tiles, 4 waves
 };
+
 
 struct GraphKey {
     const void* x; const void* noise; const void* cond; const void* ws; const void* P;
@@ -167,7 +172,10 @@ int build_plan(dad_model* m) {
                     int toff) {
         ConvOp op;
         op.name = name; op.norm = norm; op.kind = kind;
-        op.cin0 = cin0; op.cin1 = cin1; op.cin_pad = (cin0 + cin1 + 7) / 8 * 8;
+        op.cin0 = cin0; op.cin1 = cin1;
+        op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
+        const int padto = op.kc == 8 ? 8 : 32;          // KC=16 and KC=32 kernels share a packing
+        op.cin_pad = (cin0 + cin1 + padto - 1) / padto * padto;
         op.cout = cout; op.src0 = src0; op.src1 = src1; op.dst = dst; op.res = res;
         op.temb_off = toff; op.Lin = Lin;
         const int cin = cin0 + cin1;
@@ -296,15 +304,15 @@ int build_plan(dad_model* m) {
 }
 
 // ------------------------------------------------------------------------------ packing
-// Conv1d weight (co, ci, k)  ->  [ci_pad/8][k][8][M]
-std::vector<float> pack_conv(const HostTensor& w, int cin_pad, int taps) {
+// Conv1d weight (co, ci, k)  ->  [ci_pad/KC][k][M = co][KC]
+std::vector<float> pack_conv(const HostTensor& w, int cin_pad, int taps, int kc) {
     const int co = (int)w.shape[0], ci = (int)w.shape[1], k = (int)w.shape[2];
     std::vector<float> out((size_t)cin_pad * taps * co, 0.0f);
     for (int o = 0; o < co; ++o)
         for (int i = 0; i < ci; ++i)
             for (int t = 0; t < k; ++t) {
-                const size_t row = ((size_t)(i / 8) * taps + t) * 8 + (i & 7);
-                out[row * co + o] = w.data[((size_t)o * ci + i) * k + t];
+                const size_t row = ((size_t)(i / kc) * taps + t) * co + o;
+                out[row * kc + (i % kc)] = w.data[((size_t)o * ci + i) * k + t];
             }
     return out;
 }
@@ -312,20 +320,22 @@ std::vector<float> pack_conv(const HostTensor& w, int cin_pad, int taps) {
 // ConvTranspose1d weight (ci, co, 4), stride 2, pad 1:
 //   y[co, 2j]   = sum_ci W[ci,co,3] x[ci,j-1] + W[ci,co,1] x[ci,j]
 //   y[co, 2j+1] = sum_ci W[ci,co,2] x[ci,j]   + W[ci,co,0] x[ci,j+1]
-// packed as a 3-tap (offsets -1,0,+1) conv with M = 2*co rows: rows [0,co) even phase,
-// rows [co,2co) odd phase.
-std::vector<float> pack_convT(const HostTensor& w, int cin_pad) {
+// packed as a 3-tap (offsets -1,0,+1) conv with M = 2*co columns: [0,co) even phase,
+// [co,2co) odd phase.
+std::vector<float> pack_convT(const HostTensor& w, int cin_pad, int kc) {
     const int ci = (int)w.shape[0], co = (int)w.shape[1];
     const int M = 2 * co;
     std::vector<float> out((size_t)cin_pad * 3 * M, 0.0f);
     auto at = [&](int i, int o, int kk) { return w.data[((size_t)i * co + o) * 4 + kk]; };
     for (int i = 0; i < ci; ++i)
         for (int o = 0; o < co; ++o) {
-            auto row = [&](int tap) { return ((size_t)(i / 8) * 3 + tap) * 8 + (i & 7); };
-            out[row(0) * M + o] = at(i, o, 3);
-            out[row(1) * M + o] = at(i, o, 1);
-            out[row(1) * M + co + o] = at(i, o, 2);
-            out[row(2) * M + co + o] = at(i, o, 0);
+            auto slot = [&](int tap, int m) -> float& {
+                return out[(((size_t)(i / kc) * 3 + tap) * M + m) * kc + (i % kc)];
+            };
+            slot(0, o) = at(i, o, 3);
+            slot(1, o) = at(i, o, 1);
+            slot(1, co + o) = at(i, o, 2);
+            slot(2, co + o) = at(i, o, 0);
         }
     return out;
 }
@@ -351,18 +361,22 @@ void free_device(dad_model* m) {
 }
 
 // ------------------------------------------------------------------------- conv launch
+template <int CFG> struct Tile;
+template <> struct Tile<0> { static constexpr int BM = 32, BN = 64, SK = 4, KC = 32; };
+template <> struct Tile<1> { static constexpr int BM = 64, BN = 64, SK = 2, KC = 16; };
+template <> struct Tile<2> { static constexpr int BM = 128, BN = 64, SK = 1, KC = 16; };
+template <> struct Tile<3> { static constexpr int BM = 256, BN = 32, SK = 1, KC = 8; };
+template <> struct Tile<4> { static constexpr int BM = 64, BN = 64, SK = 1, KC = 16; };
+
 template <int CFG, int TAPS, int STRIDE>
-int launch_conv_t(const ConvParams& p, hipStream_t st) {
-    constexpr int BM = CFG == 0 ? 32 : CFG == 1 ? 64 : CFG == 2 ? 128 : 256;
-    constexpr int BN = 64;
-    constexpr int WM = CFG == 0 ? 1 : CFG == 1 ? 2 : 4;
-    constexpr int WN = 2;
-    constexpr int KC = CFG <= 1 ? 16 : 8;
-    auto kern = dad::conv_gemm_f32<BM, BN, WM, WN, KC, TAPS, STRIDE>;
-    const size_t lds = dad::conv_lds_floats(BM, BN, KC, TAPS, p.Lin, p.Lout) * sizeof(float);
-    const int spt = BN / p.Lout;
-    dim3 grid((p.B + spt - 1) / spt, p.M / BM);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, p);
+int launch_conv_t(ConvParams& p, hipStream_t st) {
+    using T = Tile<CFG>;
+    auto kern = dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE>;
+    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, T::KC, TAPS, p.Lin, p.Lout) * sizeof(float);
+    const int spt = T::BN / p.Lout;
+    p.ntiles_n = (p.B + spt - 1) / spt;
+    const int nblocks = p.ntiles_n * (p.M / T::BM);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (T::BM / 32) * (T::BN / 32) * T::SK), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;
 }
@@ -371,10 +385,8 @@ int launch_conv_t(const ConvParams& p, hipStream_t st) {
 // (not lazily, so that nothing but launches happens under hipGraph capture).
 template <int CFG, int TAPS, int STRIDE>
 hipError_t raise_lds_limit() {
-    constexpr int BM = CFG == 0 ? 32 : CFG == 1 ? 64 : CFG == 2 ? 128 : 256;
-    constexpr int WM = CFG == 0 ? 1 : CFG == 1 ? 2 : 4;
-    constexpr int KC = CFG <= 1 ? 16 : 8;
-    return hipFuncSetAttribute((const void*)dad::conv_gemm_f32<BM, 64, WM, 2, KC, TAPS, STRIDE>,
+    using T = Tile<CFG>;
+    return hipFuncSetAttribute((const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <int CFG>
@@ -392,7 +404,8 @@ int configure_kernels() {
     HIP_TRY(raise_lds_limit_cfg<1>());
     HIP_TRY(raise_lds_limit_cfg<2>());
     HIP_TRY(raise_lds_limit_cfg<3>());
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel<8>,
+    HIP_TRY(raise_lds_limit_cfg<4>());
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -401,7 +414,7 @@ int configure_kernels() {
 }
 
 template <int CFG>
-int launch_conv_cfg(const ConvParams& p, int taps, int stride, hipStream_t st) {
+int launch_conv_cfg(ConvParams& p, int taps, int stride, hipStream_t st) {
     if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1>(p, st);
     if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2>(p, st);
     if (taps == 3 && stride == 1) return launch_conv_t<CFG, 3, 1>(p, st);
@@ -409,26 +422,35 @@ int launch_conv_cfg(const ConvParams& p, int taps, int stride, hipStream_t st) {
     return fail(DAD_E_INVALID, "unsupported conv taps=%d stride=%d", taps, stride);
 }
 
-// Pick the M tile: it must hold whole GroupNorm groups, divide M (each phase half for the
-// transposed conv), and leave enough workgroups to cover the 256 CUs when it can.
+// Tile choice.  Hard constraints: the tile holds whole GroupNorm groups (BM % (C/8) == 0) and
+// whole samples (BN % L == 0), BM divides the columns (each phase half for the transposed
+// conv), the K chunk matches the packed weights.  Preference: enough blocks to cover the 256
+// CUs; when tiles are scarce, trade tile size for split-K depth.
 int choose_tile(const ConvOp& op, int batch) {
     const int Mrows = op.kind == CONV_UP ? op.M / 2 : op.M;
     const int cpg = op.norm.empty() ? 1 : op.cout / 8;
-    int best = -1;
-    long best_blocks = -1;
-    for (int cfg = 3; cfg >= 0; --cfg) {
+    auto valid = [&](int cfg) {
         const TileCfg& t = kTiles[cfg];
-        if (Mrows % t.BM != 0) continue;
-        if (!op.norm.empty() && (t.BM % cpg != 0)) continue;
-        if (t.BN % op.Lout != 0) continue;
+        if ((t.KC == 8) != (op.kc == 8)) return false;
+        if (Mrows % t.BM != 0) return false;
+        if (!op.norm.empty() && (t.BM % cpg != 0)) return false;
+        if (t.BN % op.Lout != 0) return false;
+        if (!op.norm.empty() && (long)(t.BM / cpg) * (t.BN / op.Lout) > 512) return false;
+        return true;
+    };
+    auto blocks = [&](int cfg) {
+        const TileCfg& t = kTiles[cfg];
         const int spt = t.BN / op.Lout;
-        if (!op.norm.empty() && (long)(t.BM / cpg) * spt > 512) continue;
-        const long blocks = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
-        // prefer the largest tile that still yields >= 512 blocks; otherwise most blocks
-        if (best < 0) { best = cfg; best_blocks = blocks; continue; }
-        if (best_blocks < 512 && blocks > best_blocks) { best = cfg; best_blocks = blocks; }
-    }
-    return best;
+        return (long)((batch + spt - 1) / spt) * (op.M / t.BM);
+    };
+    if (op.kc == 8) return valid(3) ? 3 : -1;
+    if (valid(2) && blocks(2) >= 512) return 2;          // plentiful work: big tile
+    if (valid(1) && blocks(1) >= 224) return 1;
+    if (valid(0)) return 0;
+    if (valid(1)) return 1;
+    if (valid(2)) return 2;
+    if (valid(4)) return 4;
+    return -1;
 }
 
 int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int batch, int t,
@@ -439,7 +461,6 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     ConvParams p{};
     p.src0 = op.src0 == -2 ? xext : buf(op.src0);
     p.src1 = buf(op.src1);
-    p.src_nlc = op.src0 == -2;
     p.w = op.d_w; p.bias = op.d_bias; p.gamma = op.d_gamma; p.beta = op.d_beta;
     p.temb = op.temb_off >= 0 ? m->d_temb_table + (long)t * m->plan.temb_width + op.temb_off : nullptr;
     p.res = op.res == -2 ? nullptr : buf(op.res);
@@ -471,7 +492,8 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
         case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, st); break;
         case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, st); break;
         case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, st); break;
-        default: rc = launch_conv_cfg<3>(p, op.taps, op.stride, st); break;
+        case 3: rc = launch_conv_cfg<3>(p, op.taps, op.stride, st); break;
+        default: rc = launch_conv_cfg<4>(p, op.taps, op.stride, st); break;
     }
     if (rc != DAD_OK) return rc;
     if (m->profile) HIP_TRY(hipEventRecord(e1, st));
@@ -527,13 +549,12 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         p.elem_offset = a->row_offset * (uint64_t)c.horizon * (uint64_t)c.transition_dim;
         p.draw = a->draw;
     }
-    constexpr int JB = 8;
-    const int td_pad = (c.transition_dim + JB - 1) / JB * JB;
-    const size_t lds = ((size_t)td_pad * c.dim + td_pad) * sizeof(float);
+    const size_t lds = dad::final_lds_floats(c.transition_dim, c.dim) * sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(DAD_E_INVALID, "final 1x1 conv does not fit LDS (td=%d, dim=%d)", c.transition_dim, c.dim);
     const long N = (long)batch * c.horizon;
-    const int threads = 256;
-    hipLaunchKernelGGL(dad::final_posterior_kernel<JB>, dim3((unsigned)((N + threads - 1) / threads)),
-                       dim3(threads), lds, st, p);
+    hipLaunchKernelGGL(dad::final_posterior_kernel,
+                       dim3((unsigned)((N + dad::FINAL_COLS - 1) / dad::FINAL_COLS)), dim3(256), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;
 }
@@ -650,8 +671,8 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     for (ConvOp& op : m->plan.convs) {
         const HostTensor& w = m->raw[op.name + ".weight"];
         const HostTensor& b = m->raw[op.name + ".bias"];
-        std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad)
-                                                       : pack_conv(w, op.cin_pad, op.taps);
+        std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad, op.kc)
+                                                       : pack_conv(w, op.cin_pad, op.taps, op.kc);
         int rc = upload(m, packed, &op.d_w);
         if (rc != DAD_OK) return rc;
         std::vector<float> bias = b.data;

@@ -56,7 +56,7 @@ __global__ void fill_normal_kernel(float* x, long n_elems, uint64_t elem_offset,
 
 // -------------------------------------------------------------- final conv + posterior
 struct FinalParams {
-    const float* act;        // CNL [dim][B*H]: output of final_conv[0]
+    const float* act;        // [B*H][dim] channels-last output of final_conv[0]
     const float* w;          // [td][dim] final_conv[1].weight (k=1)
     const float* bias;       // [td]
     float* x;                // (B,H,td) trajectory, updated in place unless x_out_disabled
@@ -75,57 +75,62 @@ struct FinalParams {
     uint64_t seed, elem_offset, draw;
 };
 
-template <int JB>
+constexpr int FINAL_COLS = 64;   // trajectory positions per block
+__host__ __device__ inline size_t final_lds_floats(int td, int dim) {
+    return (size_t)td * dim + td + (size_t)FINAL_COLS * (dim + 1);
+}
+
+// One block = 64 (b, l) positions.  The [64][dim] activation slab and the [td][dim] weights
+// are staged in LDS with coalesced loads; thread (col, jg) then produces outputs
+// j = jg, jg+4, ... of its position and applies the posterior update to them.
 __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams p) {
-    extern __shared__ __attribute__((aligned(16))) float ws[];   // [td_pad][dim] + [td_pad]
+    extern __shared__ __attribute__((aligned(16))) float ws[];
     const int td = p.td, dim = p.dim;
-    const int td_pad = (td + JB - 1) / JB * JB;
-    float* wl = ws;
-    float* bl = ws + td_pad * dim;
-    for (int i = threadIdx.x; i < td_pad * dim; i += blockDim.x)
-        wl[i] = (i < td * dim) ? p.w[i] : 0.0f;
-    for (int i = threadIdx.x; i < td_pad; i += blockDim.x) bl[i] = (i < td) ? p.bias[i] : 0.0f;
+    float* wl = ws;                        // [td][dim]
+    float* bl = wl + td * dim;             // [td]
+    float* tile = bl + td;                 // [64][dim+1]
+    const long N = (long)p.B * p.H;
+    const long n0 = (long)blockIdx.x * FINAL_COLS;
+    for (int i = threadIdx.x; i < td * dim; i += blockDim.x) wl[i] = p.w[i];
+    for (int i = threadIdx.x; i < td; i += blockDim.x) bl[i] = p.bias[i];
+    const int dq = dim >> 2;
+    for (int e = threadIdx.x; e < FINAL_COLS * dq; e += blockDim.x) {
+        const int row = e / dq, q = e - row * dq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + row < N) v = *reinterpret_cast<const float4*>(p.act + (n0 + row) * dim + q * 4);
+        float* d = tile + row * (dim + 1) + q * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
     __syncthreads();
 
-    const long N = (long)p.B * p.H;
-    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = threadIdx.x & (FINAL_COLS - 1);
+    const int jg = threadIdx.x / FINAL_COLS;
+    const long n = n0 + col;
     if (n >= N) return;
     const int b = (int)(n / p.H);
     const int l = (int)(n - (long)b * p.H);
-    const float* col = p.act + n;
-
-    for (int j0 = 0; j0 < td; j0 += JB) {
-        float acc[JB];
-#pragma unroll
-        for (int jj = 0; jj < JB; ++jj) acc[jj] = 0.0f;
-        for (int c = 0; c < dim; ++c) {
-            const float a = col[(long)c * N];
-#pragma unroll
-            for (int jj = 0; jj < JB; ++jj) acc[jj] = fmaf(wl[(j0 + jj) * dim + c], a, acc[jj]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < JB; ++jj) {
-            const int j = j0 + jj;
-            if (j >= td) break;
-            const long idx = n * td + j;
-            const float out = acc[jj] + bl[j];
-            if (p.eps_out != nullptr) p.eps_out[idx] = out;
-            if (p.x_out_disabled && p.mean_out == nullptr) continue;
-            const float xv = p.x[idx];
-            float x0 = p.predict_epsilon ? p.c_recip * xv - p.c_recipm1 * out : out;
-            if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-            float mean = p.coef1 * x0 + p.coef2 * xv;
-            if (p.guide != nullptr) mean = mean + p.guide_scale * p.guide[idx];
-            if (p.mean_out != nullptr) p.mean_out[idx] = mean;
-            if (p.x_out_disabled) continue;
-            const float z = (p.noise != nullptr)
-                                ? p.noise[idx]
-                                : philox_normal(p.elem_offset + (uint64_t)idx, p.draw, p.seed);
-            float xn = mean + p.sigma * z;
-            if (l == 0 && p.cond0 != nullptr)
-                xn = p.cond0[(p.cond_per_row ? (long)b * td : 0) + j];
-            p.x[idx] = xn;
-        }
+    const float* arow = tile + col * (dim + 1);
+    for (int j = jg; j < td; j += 256 / FINAL_COLS) {
+        const float* wr = wl + j * dim;
+        float acc = 0.0f;
+        for (int c = 0; c < dim; ++c) acc = fmaf(wr[c], arow[c], acc);
+        const long idx = n * td + j;
+        const float out = acc + bl[j];
+        if (p.eps_out != nullptr) p.eps_out[idx] = out;
+        if (p.x_out_disabled && p.mean_out == nullptr) continue;
+        const float xv = p.x[idx];
+        float x0 = p.predict_epsilon ? p.c_recip * xv - p.c_recipm1 * out : out;
+        if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float mean = p.coef1 * x0 + p.coef2 * xv;
+        if (p.guide != nullptr) mean = mean + p.guide_scale * p.guide[idx];
+        if (p.mean_out != nullptr) p.mean_out[idx] = mean;
+        if (p.x_out_disabled) continue;
+        const float z = (p.noise != nullptr)
+                            ? p.noise[idx]
+                            : philox_normal(p.elem_offset + (uint64_t)idx, p.draw, p.seed);
+        float xn = mean + p.sigma * z;
+        if (l == 0 && p.cond0 != nullptr) xn = p.cond0[(p.cond_per_row ? (long)b * td : 0) + j];
+        p.x[idx] = xn;
     }
 }
 
