@@ -13,7 +13,8 @@ from typing import Dict, Mapping, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdad_hip.so")
+# DAD_LIB selects an alternative build of the same ABI (timing-only ablation builds).
+LIB_PATH = os.environ.get("DAD_LIB") or os.path.join(_HERE, "libdad_hip.so")
 
 DAD_MAX_LEVELS = 8
 DAD_E_RANGE = -5

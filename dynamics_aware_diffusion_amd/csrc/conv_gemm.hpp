@@ -61,21 +61,36 @@ __device__ __forceinline__ float mish_f32(float y) {
     return y * (w / (w + 2.0f));
 }
 
+// Same function on the hardware transcendental units (v_exp_f32, v_rcp_f32: ~1 ulp each).
+// e^y = 2^(y*log2e); the product is split hi/lo so the argument reduction keeps full fp32
+// accuracy for |y| up to the softplus threshold.  Used in the conv epilogue (hot); the table
+// builders keep the libm version above.
+__device__ __forceinline__ float mish_fast_f32(float y) {
+    if (y > 20.0f) return y;
+    const float L2E_HI = 1.44269502162933349609375f;        // fp32(log2 e)
+    const float L2E_LO = 1.92596299112661746e-08f;          // log2 e - L2E_HI
+    const float t = y * L2E_HI;
+    const float tl = fmaf(y, L2E_HI, -t) + y * L2E_LO;      // rounding error of t + low part
+    const float n = __builtin_amdgcn_exp2f(t) * (1.0f + 0.693147180559945f * tl);
+    const float w = n * (n + 2.0f);
+    return y * (w * __builtin_amdgcn_rcpf(w + 2.0f));
+}
+
 // Rows of the X stage: every sample of the tile with its zero halo.
 __host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
     return (BN / Lout) * (Lin + 2 * (taps / 2));
 }
 // LDS floats of one block (the host sizes the dynamic allocation with the same formula).
 __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int taps, int Lin,
-                                                  int Lout) {
+                                                  int Lout, int SK) {
     const size_t kp = KC + 4;
     const size_t stage = ((size_t)conv_xrows(BN, Lin, Lout, taps) + (size_t)taps * BM) * kp;
-    const size_t epi = (size_t)BN * (BM + 4) + 2 * 512;
+    const size_t epi = (size_t)SK * BN * (BM + 4) + 32;
     const size_t k = 2 * stage;
     return k > epi ? k : epi;
 }
 
-template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE>
+template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32(const ConvParams p) {
     constexpr int TMW = BM / 32;                 // wave tiles along M
     constexpr int TNW = BN / 32;                 // wave tiles along N
@@ -91,6 +106,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     static_assert(KC % 8 == 0 && G % SK == 0, "K chunk must split evenly over the SK waves");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef DAD_ABLATE_NULL
+    if (p.B > 0) return;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -127,9 +145,6 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int XF = XROWS * KP;
     const int STAGE = XF + TAPS * BM * KP;       // floats per stage: [X rows][W rows]
 
-    // zero both X stages once: halo rows (and rows of samples that do not exist) stay zero,
-    // staging only ever writes real positions.
-    for (int i = tid; i < XF; i += NT) { smem[i] = 0.0f; smem[STAGE + i] = 0.0f; }
 
     // A operand (activations): lane's GEMM row n -> LDS row of tap 0
     const int n_loc = tn * 32 + l32;
@@ -137,12 +152,17 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     // B operand (weights): lane's output channel
     const int brow = XF + (tm * 32 + l32) * KP + 4 * h;
 
-    f32x16 acc;
+    // two independent accumulation chains per wave (even / odd k-steps), summed in the epilogue
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
 
     const int cin = p.cin0 + p.cin1;
+#ifdef DAD_ABLATE_NOLOOP
+    const int nchunks = 1;
+#else
     const int nchunks = p.cin_pad / KC;
+#endif
 
     // ---- staging: global -> registers (prefetch) -> LDS ---------------------------------
     constexpr int W_F4 = TAPS * BM * KC / 4;
@@ -153,22 +173,42 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int xrows_real = SPT * Lin;
     float4 wreg[W_PER_T];
     float4 xreg[X_PER_T];
+    // Per-thread staging addresses are chunk-invariant up to a uniform stride: computed once.
+    int w_goff[W_PER_T], w_loff[W_PER_T];                  // global / LDS float offsets (W)
+    int x_grow[X_PER_T], x_q4[X_PER_T], x_loff[X_PER_T];   // global row, channel quad, LDS (X)
+    constexpr int GQ = KG / 4;                              // float4 per packed row
+#pragma unroll
+    for (int i = 0; i < W_PER_T; ++i) {
+        const int e = tid + i * NT;
+        const int row = e / KQ;                             // tap*BM + m
+        const int q = e - row * KQ;
+        const int tap = row / BM;
+        const int mm = row - tap * BM;
+        const int sub = q / GQ;
+        w_goff[i] = ((sub * TAPS + tap) * M + m0 + mm) * KG + (q - sub * GQ) * 4;
+        w_loff[i] = XF + row * KP + q * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < X_PER_T; ++i) {
+        const int e = tid + i * NT;
+        const int row = e / KQ;                             // s*Lin + l
+        const int q = e - row * KQ;
+        const int s = row / Lin;
+        const int l = row - s * Lin;
+        const bool ok = e < xrows_real * KQ && s < nvalid;
+        x_grow[i] = ok ? s0 * Lin + row : -1;
+        x_q4[i] = q * 4;
+        x_loff[i] = e < xrows_real * KQ ? (s * SEG + PAD + l) * KP + q * 4 : -1;
+    }
+    const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
 
     auto load_stage = [&](int chunk) {
-        constexpr int GQ = KG / 4;                          // float4 per packed row
+        const float* wsrc = p.w + chunk * w_chunk_stride;
 #pragma unroll
         for (int i = 0; i < W_PER_T; ++i) {
-            const int e = tid + i * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (W_F4 % NT == 0 || e < W_F4) {
-                const int row = e / KQ;                         // tap*BM + m
-                const int q = e - row * KQ;
-                const int tap = row / BM;
-                const int mm = row - tap * BM;
-                const int sub = q / GQ;
-                const long grow = ((long)(chunk * NSUB + sub) * TAPS + tap) * M + m0 + mm;
-                v = *reinterpret_cast<const float4*>(p.w + grow * KG + (q - sub * GQ) * 4);
-            }
+            if (W_F4 % NT == 0 || tid + i * NT < W_F4)
+                v = *reinterpret_cast<const float4*>(wsrc + w_goff[i]);
             wreg[i] = v;
         }
         const int c0 = chunk * KC;
@@ -178,23 +218,18 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int cb = second ? c0 - p.cin0 : c0;
 #pragma unroll
         for (int i = 0; i < X_PER_T; ++i) {
-            const int e = tid + i * NT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < xrows_real * KQ) {
-                const int row = e / KQ;                   // s*Lin + l
-                const int q = e - row * KQ;
-                const int s = row / Lin;
-                if (s < nvalid) {
-                    const float* g = xsrc + ((long)s0 * Lin + row) * cs + cb + q * 4;
-                    const int left = cs - (cb + q * 4);   // channels remaining in this source
-                    if ((cs & 3) == 0 && left >= 4) {
-                        v = *reinterpret_cast<const float4*>(g);
-                    } else {                              // ragged tail (first layer: cin = td)
-                        if (left > 0) v.x = g[0];
-                        if (left > 1) v.y = g[1];
-                        if (left > 2) v.z = g[2];
-                        if (left > 3) v.w = g[3];
-                    }
+            if (x_grow[i] >= 0) {
+                const int cc = cb + x_q4[i];
+                const float* g = xsrc + (long)x_grow[i] * cs + cc;
+                if (!RAGGED) {
+                    v = *reinterpret_cast<const float4*>(g);
+                } else {                                  // first layer: cin = transition_dim
+                    const int left = cs - cc;             // channels remaining in this source
+                    if (left > 0) v.x = g[0];
+                    if (left > 1) v.y = g[1];
+                    if (left > 2) v.z = g[2];
+                    if (left > 3) v.w = g[3];
                 }
             }
             xreg[i] = v;
@@ -203,149 +238,206 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     auto store_stage = [&](int stage) {
         const int base = stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < W_PER_T; ++i) {
-            const int e = tid + i * NT;
-            if (W_F4 % NT == 0 || e < W_F4) {
-                const int row = e / KQ;                   // tap*BM + m
-                const int q = e - row * KQ;
-                *reinterpret_cast<float4*>(&smem[base + XF + row * KP + q * 4]) = wreg[i];
-            }
-        }
+        for (int i = 0; i < W_PER_T; ++i)
+            if (W_F4 % NT == 0 || tid + i * NT < W_F4)
+                *reinterpret_cast<float4*>(&smem[base + w_loff[i]]) = wreg[i];
 #pragma unroll
-        for (int i = 0; i < X_PER_T; ++i) {
-            const int e = tid + i * NT;
-            if (e < xrows_real * KQ) {
-                const int row = e / KQ;
-                const int q = e - row * KQ;
-                const int s = row / Lin;
-                const int l = row - s * Lin;
-                *reinterpret_cast<float4*>(&smem[base + (s * SEG + PAD + l) * KP + q * 4]) = xreg[i];
-            }
-        }
+        for (int i = 0; i < X_PER_T; ++i)
+            if (x_loff[i] >= 0) *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = xreg[i];
     };
     (void)cin;
 
-    __syncthreads();                       // zero fill done before real rows land
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
+    // ---- main loop -------------------------------------------------------------------------
+    // Software pipeline (explicit, the compiler does not build it):
+    //   * global -> register prefetch runs TWO chunks ahead: the loads of chunk c+2 are issued
+    //     right after the registers of chunk c+1 were drained into LDS, and are not needed
+    //     until a whole chunk of MFMAs later;
+    //   * MFMA operand fragments are read one unit (4 MFMAs) ahead, so every ds_read_b128 has
+    //     >= 256 matrix-pipe cycles to land;
+    //   * the chunk's single barrier sits in FRONT of its last unit's MFMAs: the first
+    //     fragments of the next chunk are fetched behind the barrier while those MFMAs run, so
+    //     the matrix pipe does not drain at the barrier.
+    constexpr int UW = TAPS * GW;                       // units (4 MFMAs each) per wave per chunk
+    const int koff = ks * (GW * 8);                     // this wave's channel groups in a chunk
+    const int afrag = arow + koff;
+    const int bfrag = brow + koff;
+    auto frag_a = [&](int stage, int u) -> float4 {
+        const int tap = u / GW, gw = u - tap * GW;
+        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * 8]);
+    };
+    auto frag_b = [&](int stage, int u) -> float4 {
+        const int tap = u / GW, gw = u - tap * GW;
+        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * 8]);
+    };
 
-    const int koff = ks * (GW * 8);        // this wave's channel groups inside the chunk
+    load_stage(0);                         // first global loads fly while LDS is being zeroed
+    // zero both X stages once: halo rows (and rows of samples that do not exist) stay zero,
+    // staging only ever writes real positions.  (XF is a multiple of 4 floats.)
+    for (int i = tid * 4; i < XF; i += NT * 4) {
+        *reinterpret_cast<float4*>(&smem[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&smem[STAGE + i]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();                       // zero fill done before real rows land
+    store_stage(0);
+    if (nchunks > 1) load_stage(1);
+    __syncthreads();
+    float4 ca = frag_a(0, 0), cb = frag_b(0, 0);
+
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        const bool more = (ch + 1) < nchunks;
-        if (more) load_stage(ch + 1);                    // global loads in flight under MFMA
-        const int abase = cur * STAGE + arow + koff;
-        const int bbase = cur * STAGE + brow + koff;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-            for (int gw = 0; gw < GW; ++gw) {
-                const float4 a = *reinterpret_cast<const float4*>(&smem[abase + tap * KP + gw * 8]);
-                const float4 b = *reinterpret_cast<const float4*>(&smem[bbase + tap * BM * KP + gw * 8]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        for (int u = 0; u < UW; ++u) {
+            float4 na = ca, nb = cb;
+            if (u + 1 < UW) {
+                na = frag_a(cur, u + 1);
+                nb = frag_b(cur, u + 1);
+            } else {
+                if (ch + 1 < nchunks) store_stage(cur ^ 1);
+                __syncthreads();
+                if (ch + 2 < nchunks) load_stage(ch + 2);
+                if (ch + 1 < nchunks) {
+                    na = frag_a(cur ^ 1, 0);
+                    nb = frag_b(cur ^ 1, 0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ca = na;
+            cb = nb;
         }
-        if (more) store_stage(cur ^ 1);
-        __syncthreads();
     }
+    __syncthreads();                       // all MFMAs retired before the stage memory is reused
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 
-    // ---- epilogue through LDS: E[n][m] -----------------------------------------------------
+    // ---- epilogue ---------------------------------------------------------------------------
+    // 1. every wave drops its accumulators into its split-K copy of the tile E[ks][n][m] (LDS);
+    // 2. after ONE barrier each thread owns F4PL float4 (4 channels x 1 position) of one
+    //    (GroupNorm group, sample) pair: it folds the copies and the bias into registers,
+    //    takes part in the pair's mean / variance reductions (two-pass, fp32, fixed order:
+    //    xor-shuffles inside the wave, an LDS hop when a pair spans several waves), then
+    //    normalises, applies Mish, adds time embedding / residual and stores — without touching
+    //    LDS again.
     constexpr int ES = BM + 4;
-    float* E = smem;                                   // [BN][ES]
-    float* stat_mean = smem + BN * ES;                 // [<=512]
-    float* stat_rstd = stat_mean + 512;
-#pragma unroll
-    for (int s = 0; s < SK; ++s) {
-        if (ks == s) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = tm * 32 + l32;
-                float* e = &E[row * ES + col];
-                if (s == 0) *e = acc[r] + p.bias[m0 + col];
-                else *e += acc[r];
-            }
-        }
-        __syncthreads();
-    }
-
+    constexpr int ECOPY = BN * ES;
+    constexpr int F4PL = (BN * BM / 4) / NT;           // float4 per thread
+    static_assert(F4PL >= 1 && (BN * BM / 4) % NT == 0, "epilogue mapping");
+    float* E = smem;                                   // [SK][BN][ES]
+    float* red = smem + SK * ECOPY;                    // [2][waves] cross-wave partials
+#ifdef DAD_ABLATE_NOEPI
+    if (p.B > 0) { if (acc[0] == 123.456f) p.dst[0] = acc[1]; return; }
+#endif
+#ifdef DAD_ABLATE_GN
+    const bool has_gn = false;
+#else
     const bool has_gn = p.gamma != nullptr;
-    if (has_gn) {
-        // (group, sample) pairs of this tile; two-pass mean / biased variance in fp32.
-        const int cpg = p.cpg;
-        const int gpt = BM / cpg;
-        const int pairs = gpt * SPT;
-        const int cnt = cpg * Lout;
-        int tpp = NT / pairs;
-        tpp = tpp < 1 ? 1 : (tpp > 64 ? 64 : tpp);
-        tpp = 1 << (31 - __clz(tpp));                  // power of two
-        const int ppr = NT / tpp;
-        const int sub = tid & (tpp - 1);
-        const int cshift = 31 - __clz(cpg);
-        for (int pr = tid / tpp; pr < pairs; pr += ppr) {
-            const int g = pr / SPT;
-            const int s = pr - g * SPT;
-            const float* base = E + (s * Lout) * ES + g * cpg;
-            float sum = 0.0f;
-            for (int e = sub; e < cnt; e += tpp) sum += base[(e >> cshift) * ES + (e & (cpg - 1))];
-            for (int o = tpp >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum / (float)cnt;
-            float sq = 0.0f;
-            for (int e = sub; e < cnt; e += tpp) {
-                const float d = base[(e >> cshift) * ES + (e & (cpg - 1))] - mean;
-                sq += d * d;
-            }
-            for (int o = tpp >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-            if (sub == 0) {
-                stat_mean[pr] = mean;
-                stat_rstd[pr] = 1.0f / sqrtf(sq / (float)cnt + 1e-5f);
-            }
-        }
-        __syncthreads();
-    }
-
-    // normalise + Mish + adds + coalesced store (float4 along channels)
-    constexpr int BM4 = BM / 4;
-    for (int e = tid; e < BN * BM4; e += NT) {
-        const int row = e / BM4;                       // n within tile
-        const int c4 = (e - row * BM4) * 4;            // channel within tile
-        const int s = row >> p.lshift;
-        if (s >= nvalid) continue;
-        const int l = row & (Lout - 1);
-        const int m = m0 + c4;
-        const float4 v = *reinterpret_cast<const float4*>(E + row * ES + c4);
-        float y[4] = {v.x, v.y, v.z, v.w};
-        if (has_gn) {
-            const int pr = (c4 / p.cpg) * SPT + s;
-            const float mu = stat_mean[pr], rs = stat_rstd[pr];
-            const float4 ga = *reinterpret_cast<const float4*>(p.gamma + m);
-            const float4 be = *reinterpret_cast<const float4*>(p.beta + m);
-            y[0] = mish_f32((y[0] - mu) * rs * ga.x + be.x);
-            y[1] = mish_f32((y[1] - mu) * rs * ga.y + be.y);
-            y[2] = mish_f32((y[2] - mu) * rs * ga.z + be.z);
-            y[3] = mish_f32((y[3] - mu) * rs * ga.w + be.w);
-        }
-        if (p.temb != nullptr) {
-            const float4 tv = *reinterpret_cast<const float4*>(p.temb + m);
-            y[0] += tv.x; y[1] += tv.y; y[2] += tv.z; y[3] += tv.w;
-        }
-        long off;
+#endif
+    // ownership: GroupNorm -> lanes of a pair are contiguous; otherwise plain row-major
+    const int cpg = has_gn ? p.cpg : BM;
+    const int cq = cpg >> 2;                           // float4 per row of a pair
+    const int cnt4 = has_gn ? (Lout * cq) : (BN * cq); // float4 per pair
+    const int lpp = cnt4 / F4PL;                       // lanes per pair (power of two >= 1)
+    const int gpt = BM / cpg;
+    const int pr = tid / lpp;
+    const int lp = tid - pr * lpp;
+    const int ps = has_gn ? pr / gpt : 0;              // sample of the pair
+    const int pg = has_gn ? pr - ps * gpt : 0;         // group of the pair
+    int erow[F4PL], ecol[F4PL];
+    long eoff[F4PL];
+    float4 bias4[F4PL], gam4[F4PL], bet4[F4PL], add4[F4PL];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < F4PL; ++k) {
+        const int j = lp + k * lpp;                    // float4 index inside the pair
+        const int r = j / cq;
+        erow[k] = ps * Lout + r;                       // tile row (position)
+        ecol[k] = pg * cpg + (j - r * cq) * 4;         // tile column (channel)
+        const int s = erow[k] >> p.lshift;
+        const int l = erow[k] & (Lout - 1);
+        const int em = m0 + ecol[k];
+        bias4[k] = *reinterpret_cast<const float4*>(p.bias + em);
+        gam4[k] = has_gn ? *reinterpret_cast<const float4*>(p.gamma + em) : zero4;
+        bet4[k] = has_gn ? *reinterpret_cast<const float4*>(p.beta + em) : zero4;
+        add4[k] = p.temb != nullptr ? *reinterpret_cast<const float4*>(p.temb + em) : zero4;
         if (!p.interleave) {
-            off = ((long)(s0 + s) * Lout + l) * M + m;
-            if (p.res != nullptr) {
-                const float4 r = *reinterpret_cast<const float4*>(p.res + off);
-                y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
+            eoff[k] = ((long)(s0 + s) * Lout + l) * M + em;
+            if (p.res != nullptr && s < nvalid) {
+                const float4 rv = *reinterpret_cast<const float4*>(p.res + eoff[k]);
+                add4[k].x += rv.x; add4[k].y += rv.y; add4[k].z += rv.z; add4[k].w += rv.w;
             }
         } else {
             const int half = M >> 1;
-            const int phase = m >= half;
-            off = ((long)(s0 + s) * (2 * Lout) + 2 * l + phase) * half + (m - phase * half);
+            const int phase = em >= half;
+            eoff[k] = ((long)(s0 + s) * (2 * Lout) + 2 * l + phase) * half + (em - phase * half);
         }
-        *reinterpret_cast<float4*>(p.dst + off) = make_float4(y[0], y[1], y[2], y[3]);
+        if (s >= nvalid) eoff[k] = -1;
+    }
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = tm * 32 + l32;
+        E[ks * ECOPY + row * ES + col] = acc[r];
+    }
+    __syncthreads();
+
+    float y[F4PL][4];
+#pragma unroll
+    for (int k = 0; k < F4PL; ++k) {
+        const float* q = E + erow[k] * ES + ecol[k];
+        float4 v = *reinterpret_cast<const float4*>(q);
+#pragma unroll
+        for (int c = 1; c < SK; ++c) {
+            const float4 u = *reinterpret_cast<const float4*>(q + c * ECOPY);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        y[k][0] = v.x + bias4[k].x; y[k][1] = v.y + bias4[k].y;
+        y[k][2] = v.z + bias4[k].z; y[k][3] = v.w + bias4[k].w;
+    }
+
+    if (has_gn) {
+        const float inv_cnt = 1.0f / (float)(cnt4 * 4);
+        const int width = lpp < 64 ? lpp : 64;
+        const int wpp = lpp >> 6;                      // waves per pair when a pair spans waves
+        auto pair_sum = [&](float v, int slot) -> float {
+            for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (wpp > 1) {                             // block-uniform branch
+                if (lane == 0) red[slot * 16 + wave] = v;
+                __syncthreads();
+                const int w0 = (wave / wpp) * wpp;
+                v = 0.0f;
+                for (int w = 0; w < wpp; ++w) v += red[slot * 16 + w0 + w];
+            }
+            return v;
+        };
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < F4PL; ++k) sum += (y[k][0] + y[k][1]) + (y[k][2] + y[k][3]);
+        const float mean = pair_sum(sum, 0) * inv_cnt;
+        float sq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < F4PL; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float d = y[k][c] - mean; sq += d * d; }
+        const float rstd = 1.0f / sqrtf(pair_sum(sq, 1) * inv_cnt + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < F4PL; ++k) {
+            y[k][0] = mish_fast_f32((y[k][0] - mean) * rstd * gam4[k].x + bet4[k].x);
+            y[k][1] = mish_fast_f32((y[k][1] - mean) * rstd * gam4[k].y + bet4[k].y);
+            y[k][2] = mish_fast_f32((y[k][2] - mean) * rstd * gam4[k].z + bet4[k].z);
+            y[k][3] = mish_fast_f32((y[k][3] - mean) * rstd * gam4[k].w + bet4[k].w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < F4PL; ++k) {
+        if (eoff[k] < 0) continue;
+        *reinterpret_cast<float4*>(p.dst + eoff[k]) =
+            make_float4(y[k][0] + add4[k].x, y[k][1] + add4[k].y, y[k][2] + add4[k].z,
+                        y[k][3] + add4[k].w);
     }
 }
 

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -83,10 +84,13 @@ struct TileCfg { int BM, BN, SK, KC; };
 // configuration runs 8 waves per block except the last (4 waves, two blocks per CU).
 const TileCfg kTiles[] = {
     {32, 64, 4, 32},    // 0: few output tiles -> deepest split-K
-    {64, 64, 2, 16},    // 1: the workhorse at batch 256
+    {64, 64, 2, 32},    // 1: the workhorse at batch 256
     {128, 64, 1, 16},   // 2: GroupNorm groups of 128 channels / plentiful tiles
     {256, 32, 1, 8},    // 3: GroupNorm groups of 256 channels (C = 2048)
     {64, 64, 1, 16},    // 4: plentiful tiles, 4 waves
+    {32, 64, 2, 16},    // 5: 4 waves, small LDS: several independent blocks per CU
+    {32, 64, 1, 16},    // 6: 2 waves
+    {64, 64, 2, 16},    // 7: as 1 with the shallower K chunk (two blocks per CU fit)
 };
 
 
@@ -363,16 +367,24 @@ void free_device(dad_model* m) {
 // ------------------------------------------------------------------------- conv launch
 template <int CFG> struct Tile;
 template <> struct Tile<0> { static constexpr int BM = 32, BN = 64, SK = 4, KC = 32; };
-template <> struct Tile<1> { static constexpr int BM = 64, BN = 64, SK = 2, KC = 16; };
+template <> struct Tile<1> { static constexpr int BM = 64, BN = 64, SK = 2, KC = 32; };
 template <> struct Tile<2> { static constexpr int BM = 128, BN = 64, SK = 1, KC = 16; };
 template <> struct Tile<3> { static constexpr int BM = 256, BN = 32, SK = 1, KC = 8; };
 template <> struct Tile<4> { static constexpr int BM = 64, BN = 64, SK = 1, KC = 16; };
+template <> struct Tile<5> { static constexpr int BM = 32, BN = 64, SK = 2, KC = 16; };
+template <> struct Tile<6> { static constexpr int BM = 32, BN = 64, SK = 1, KC = 16; };
+template <> struct Tile<7> { static constexpr int BM = 64, BN = 64, SK = 2, KC = 16; };
 
 template <int CFG, int TAPS, int STRIDE>
 int launch_conv_t(ConvParams& p, hipStream_t st) {
     using T = Tile<CFG>;
-    auto kern = dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE>;
-    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, T::KC, TAPS, p.Lin, p.Lout) * sizeof(float);
+    const bool ragged = (p.cin0 & 3) != 0;
+    if (ragged && !(STRIDE == 1 && (TAPS == 5 || TAPS == 1)))
+        return fail(DAD_E_INVALID, "ragged channel count only supported for the first block");
+    auto kern = (ragged && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
+                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, 1, true>
+                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE, false>;
+    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, T::KC, TAPS, p.Lin, p.Lout, T::SK) * sizeof(float);
     const int spt = T::BN / p.Lout;
     p.ntiles_n = (p.B + spt - 1) / spt;
     const int nblocks = p.ntiles_n * (p.M / T::BM);
@@ -386,8 +398,15 @@ int launch_conv_t(ConvParams& p, hipStream_t st) {
 template <int CFG, int TAPS, int STRIDE>
 hipError_t raise_lds_limit() {
     using T = Tile<CFG>;
-    return hipFuncSetAttribute((const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(
+        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE, false>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    if (STRIDE == 1 && (TAPS == 5 || TAPS == 1))
+        e = hipFuncSetAttribute(
+            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, 1, true>,
+            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
 }
 template <int CFG>
 hipError_t raise_lds_limit_cfg() {
@@ -405,6 +424,9 @@ int configure_kernels() {
     HIP_TRY(raise_lds_limit_cfg<2>());
     HIP_TRY(raise_lds_limit_cfg<3>());
     HIP_TRY(raise_lds_limit_cfg<4>());
+    HIP_TRY(raise_lds_limit_cfg<5>());
+    HIP_TRY(raise_lds_limit_cfg<6>());
+    HIP_TRY(raise_lds_limit_cfg<7>());
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4>,
@@ -435,7 +457,9 @@ int choose_tile(const ConvOp& op, int batch) {
         if (Mrows % t.BM != 0) return false;
         if (!op.norm.empty() && (t.BM % cpg != 0)) return false;
         if (t.BN % op.Lout != 0) return false;
-        if (!op.norm.empty() && (long)(t.BM / cpg) * (t.BN / op.Lout) > 512) return false;
+        const int nthreads = 64 * (t.BM / 32) * (t.BN / 32) * t.SK;
+        const int f4pl = t.BM * t.BN / 4 / nthreads;
+        if (!op.norm.empty() && op.Lout * cpg / 4 < f4pl) return false;   // >= 1 lane per (group, sample)
         return true;
     };
     auto blocks = [&](int cfg) {
@@ -444,6 +468,8 @@ int choose_tile(const ConvOp& op, int batch) {
         return (long)((batch + spt - 1) / spt) * (op.M / t.BM);
     };
     if (op.kc == 8) return valid(3) ? 3 : -1;
+    static const char* force = getenv("DAD_TILE");       // tuning hook: force a tile if valid
+    if (force && valid(atoi(force))) return atoi(force);
     if (valid(2) && blocks(2) >= 512) return 2;          // plentiful work: big tile
     if (valid(1) && blocks(1) >= 224) return 1;
     if (valid(0)) return 0;
@@ -493,7 +519,10 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
         case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, st); break;
         case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, st); break;
         case 3: rc = launch_conv_cfg<3>(p, op.taps, op.stride, st); break;
-        default: rc = launch_conv_cfg<4>(p, op.taps, op.stride, st); break;
+        case 4: rc = launch_conv_cfg<4>(p, op.taps, op.stride, st); break;
+        case 5: rc = launch_conv_cfg<5>(p, op.taps, op.stride, st); break;
+        case 6: rc = launch_conv_cfg<6>(p, op.taps, op.stride, st); break;
+        default: rc = launch_conv_cfg<7>(p, op.taps, op.stride, st); break;
     }
     if (rc != DAD_OK) return rc;
     if (m->profile) HIP_TRY(hipEventRecord(e1, st));
