@@ -62,12 +62,24 @@ def build_policy(arch: str, device: torch.device):
     return policy, diff, {0: cond.to(device)}, state
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(arch: str, batch: int, state, budget_s: float = 15.0):
     """Time the oracle's denoise step on the host cores (bounded sample, extrapolated x T)."""
     from oracle import denoiser as od_
     od, ad, dim, mults, T = synth.ARCHS[arch]
     td = od + ad
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     w = {k: torch.from_numpy(v) for k, v in state.items()}
     sched = od_.schedule_buffers("cosine", T)

@@ -70,6 +70,7 @@ ABI = {
                               C.c_int32, C.c_void_p]),
     "dad_fill_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64,
                                   C.c_uint64, C.c_void_p]),
+    "dad_debug_set_tile": (C.c_int, [C.c_int32]),
     "dad_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_double)]),

@@ -20,6 +20,7 @@
 namespace {
 
 thread_local char g_err[1024] = "";
+int g_force_tile = -1;      // dad_debug_set_tile: tuning / test hook
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -123,6 +124,7 @@ struct dad_model {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double prof_flops = 0;
+    int64_t prof_launches = 0;
     // graphs
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
@@ -468,8 +470,7 @@ int choose_tile(const ConvOp& op, int batch) {
         return (long)((batch + spt - 1) / spt) * (op.M / t.BM);
     };
     if (op.kc == 8) return valid(3) ? 3 : -1;
-    static const char* force = getenv("DAD_TILE");       // tuning hook: force a tile if valid
-    if (force && valid(atoi(force))) return atoi(force);
+    if (g_force_tile >= 0 && g_force_tile < 8 && valid(g_force_tile)) return g_force_tile;
     if (valid(2) && blocks(2) >= 512) return 2;          // plentiful work: big tile
     if (valid(1) && blocks(1) >= 224) return 1;
     if (valid(0)) return 0;
@@ -499,20 +500,6 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     if (cfg < 0)
         return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
                     op.name.c_str(), op.M, op.cout / 8, op.Lout);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (m->profile) {
-        if (m->ev_used == m->ev_pool.size()) {
-            hipEvent_t a, b;
-            HIP_TRY(hipEventCreate(&a));
-            HIP_TRY(hipEventCreate(&b));
-            m->ev_pool.push_back({a, b});
-        }
-        e0 = m->ev_pool[m->ev_used].first;
-        e1 = m->ev_pool[m->ev_used].second;
-        ++m->ev_used;
-        m->prof_flops += op.flops_per_sample * batch;
-        HIP_TRY(hipEventRecord(e0, st));
-    }
     int rc;
     switch (cfg) {
         case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, st); break;
@@ -524,9 +511,7 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
         case 6: rc = launch_conv_cfg<6>(p, op.taps, op.stride, st); break;
         default: rc = launch_conv_cfg<7>(p, op.taps, op.stride, st); break;
     }
-    if (rc != DAD_OK) return rc;
-    if (m->profile) HIP_TRY(hipEventRecord(e1, st));
-    return DAD_OK;
+    return rc;
 }
 
 int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
@@ -544,10 +529,28 @@ int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
 }
 
 int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStream_t st) {
+    // Profiling brackets the whole run of conv-GEMM launches of one denoiser evaluation with
+    // ONE pair of HIP events on the launch stream (events between individual launches would
+    // break the back-to-back dispatch they are meant to time).
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->profile) {
+        if (m->ev_used == m->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            m->ev_pool.push_back({a, b});
+        }
+        e0 = m->ev_pool[m->ev_used].first;
+        e1 = m->ev_pool[m->ev_used].second;
+        ++m->ev_used;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
     for (const ConvOp& op : m->plan.convs) {
         const int rc = run_conv(m, op, x, ws, batch, t, st);
         if (rc != DAD_OK) return rc;
+        if (m->profile) { m->prof_flops += op.flops_per_sample * batch; ++m->prof_launches; }
     }
+    if (m->profile) HIP_TRY(hipEventRecord(e1, st));
     return DAD_OK;
 }
 
@@ -873,11 +876,17 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, u
     return DAD_OK;
 }
 
+int dad_debug_set_tile(int32_t cfg) {
+    g_force_tile = cfg;
+    return DAD_OK;
+}
+
 int dad_profile_enable(dad_model* m, int32_t on) {
     if (!m) return fail(DAD_E_INVALID, "null model");
     m->profile = on != 0;
     m->ev_used = 0;
     m->prof_flops = 0;
+    m->prof_launches = 0;
     return DAD_OK;
 }
 
@@ -891,10 +900,11 @@ int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, doub
         ms += d;
     }
     if (conv_ms) *conv_ms = ms;
-    if (conv_launches) *conv_launches = (int64_t)m->ev_used;
+    if (conv_launches) *conv_launches = m->prof_launches;
     if (conv_flops) *conv_flops = m->prof_flops;
     m->ev_used = 0;
     m->prof_flops = 0;
+    m->prof_launches = 0;
     return DAD_OK;
 }
 

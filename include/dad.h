@@ -150,10 +150,17 @@ int dad_project(const dad_project_args* p, float alpha, float* x, int32_t batch,
 int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed,
                     uint64_t row_offset, uint64_t draw, dad_stream_t stream);
 
-/* Optional per-kernel timing: when enabled every conv-GEMM launch is bracketed by HIP
- * events on the launch stream; dad_profile_read synchronises, sums and resets them. */
+/* Optional kernel timing: when enabled, the run of conv-GEMM launches of every denoiser
+ * evaluation is bracketed by one pair of HIP events on the launch stream;
+ * dad_profile_read synchronises, returns the summed duration, the number of conv-GEMM
+ * launches inside the brackets and their algorithmic FLOPs, and resets the counters. */
 int dad_profile_enable(dad_model* m, int32_t on);
 int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops);
+
+/* Test / tuning hook: force conv tile configuration `cfg` (0..7, see kTiles in
+ * csrc/dad_lib.hip) wherever it is valid for a layer; -1 restores the heuristic.  Results
+ * do not depend on the tile beyond fp32 summation order. */
+int dad_debug_set_tile(int32_t cfg);
 
 #ifdef __cplusplus
 }

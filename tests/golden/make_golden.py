@@ -307,7 +307,26 @@ def gen_glue():
     save("glue", **out)
 
 
+def gen_keys():
+    """state_dict key -> shape of the reference GaussianDiffusion for every architecture."""
+    import json
+    out = {}
+    for net in ("tiny", "tiny4", "pointmaze", "halfcheetah", "door"):
+        od, ad, td, dim, mults = cases.net_dims(net)
+        with torch.device("meta"):
+            unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults))
+        sd = {("model." + k): list(v.shape) for k, v in unet.state_dict().items()}
+        diff = GaussianDiffusion(ref_unet.TemporalUnet(6, dim=32, dim_mults=(1, 2)), cases.H, od, ad,
+                                 n_timesteps=cases.NETS[net][4])
+        bufs = {k: list(v.shape) for k, v in diff.state_dict().items() if not k.startswith("model.")}
+        out[net] = {"buffers": bufs, "model": sd, "order": list(bufs) + list(sd)}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("  wrote state_dict_keys.json")
+
+
 SECTIONS = {
+    "keys": gen_keys,
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
     "forward": gen_forward, "loops": gen_loops, "guidance": gen_guidance,
     "projection": gen_projection, "glue": gen_glue,

@@ -1,0 +1,238 @@
+"""GPU tests beyond the golden vectors: every conv tile variant, ragged / edge batch sizes,
+per-row conditions, the in-kernel noise generator, sharding invariance, the opt-in projection
+inside the loop, and size-independent properties at the benchmark's full batch."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as orc
+from oracle import philox as ophilox
+from oracle import projection as oproj
+from tests.golden import cases
+from tests.test_hip_parity import TOL_LOOP, TOL_STEP, build, eps_gain
+from tests.util import golden, max_abs, net_weights_torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _oracle_eps(net, x, t):
+    with torch.no_grad():
+        return orc.unet_forward(net_weights_torch(net), x, torch.full((x.shape[0],), t, dtype=torch.long))
+
+
+@pytest.mark.parametrize("tile", list(range(8)))
+def test_every_tile_variant_matches_oracle(tile, dev):
+    """Force each (BM, BN, split-K, K-chunk) instantiation wherever it is valid."""
+    from dynamics_aware_diffusion_amd import _engine
+    from dynamics_aware_diffusion_amd.utils import synth
+    lib = _engine.load_library()
+    try:
+        lib.dad_debug_set_tile(tile)
+        for net, B in (("tiny", 5), ("pointmaze", 9)):
+            diff = build(net, cases.NETS[net][4], "cosine", dev)
+            x = torch.from_numpy(synth.normal_like(61, f"tile{tile}.{net}", (B, 32, diff.transition_dim)))
+            want = _oracle_eps(net, x, 3)
+            got = diff.model(x.to(dev), 3)
+            torch.cuda.synchronize()
+            assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, (tile, net)
+    finally:
+        lib.dad_debug_set_tile(-1)
+
+
+def test_wide_group_tiles_on_big_architectures(dev):
+    """HalfCheetah / Door exercise the 128- and 256-channel GroupNorm tiles (cfg 2 and 3)."""
+    for name, net, B, t in cases.FORWARD_CASES[3:]:
+        g = golden(name)
+        diff = build(net, cases.NETS[net][4], "cosine", dev)
+        x = torch.from_numpy(cases.forward_input(name, net, B)).to(dev)
+        got = diff.model(x, t).cpu().numpy()
+        assert max_abs(got, g["eps"]) <= TOL_STEP
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 7, 17, 65])
+def test_ragged_batches_match_oracle(B, dev):
+    from dynamics_aware_diffusion_amd.utils import synth
+    diff = build("tiny4", 20, "cosine", dev)          # 4 levels: L = 32,16,8,4
+    x = torch.from_numpy(synth.normal_like(62, f"ragged.{B}", (B, 32, diff.transition_dim)))
+    got = diff.model(x.to(dev), 11)
+    torch.cuda.synchronize()
+    assert max_abs(got.cpu().numpy(), _oracle_eps("tiny4", x, 11).numpy()) <= TOL_STEP
+
+
+def test_per_row_conditions_and_outputs(dev):
+    """(B, td) conditions (one per environment) + eps/mean side outputs of one step."""
+    from dynamics_aware_diffusion_amd.utils import synth
+    net, T, B = "tiny", 20, 6
+    diff = build(net, T, "cosine", dev)
+    eng = diff._engine(dev)
+    w, sched = net_weights_torch(net), orc.schedule_buffers("cosine", T)
+    x = torch.from_numpy(synth.normal_like(63, "rowcond.x", (B, 32, 6)))
+    z = torch.from_numpy(synth.normal_like(63, "rowcond.z", (B, 32, 6)))
+    cond = torch.from_numpy(synth.uniform(63, "rowcond.c", (B, 6), 0.9))
+    t = 7
+    tt = torch.full((B,), t, dtype=torch.long)
+    with torch.no_grad():
+        mean, _, eps = orc.p_mean_variance(w, sched, x, tt)
+        want = orc.denoise_step(w, sched, x.clone(), tt, z, {0: cond})
+    xd = x.to(dev).clone()
+    mean_d, eps_d = torch.empty_like(xd), torch.empty_like(xd)
+    eng.denoise_step(xd, t, noise=z.to(dev), cond0=cond.to(dev), mean_out=mean_d, eps_out=eps_d)
+    torch.cuda.synchronize()
+    tol = TOL_STEP * eps_gain(diff, t)
+    assert max_abs(eps_d.cpu().numpy(), eps.numpy()) <= TOL_STEP
+    assert max_abs(mean_d.cpu().numpy(), mean.numpy()) <= tol
+    assert max_abs(xd.cpu().numpy(), want.numpy()) <= tol
+    assert torch.equal(xd[:, 0].cpu(), cond)
+    # t == 0: noise is masked, result is the mean (+ inpainting)
+    x0 = x.to(dev).clone()
+    eng.denoise_step(x0, 0, noise=torch.full_like(x0, 1e6))
+    assert torch.isfinite(x0).all() and x0.abs().max() < 50
+
+
+def test_inkernel_philox_matches_its_oracle(dev):
+    diff = build("tiny", 20, "cosine", dev)
+    eng = diff._engine(dev)
+    B, E = 37, 32 * 6
+    for draw, seed, off in ((0, 1, 0), (5, 0xDEADBEEF12345678, 11)):
+        x = torch.empty(B, 32, 6, device=dev)
+        eng.fill_normal(x, seed, row_offset=off, draw=draw)
+        idx = np.arange(B * E, dtype=np.uint64) + np.uint64(off * E)
+        want = ophilox.normal(idx, draw, seed).reshape(B, 32, 6)
+        assert max_abs(x.cpu().numpy(), want) <= 2e-5        # float stage: libm vs device
+    big = torch.empty(4096, 32, 6, device=dev)
+    eng.fill_normal(big, 7)
+    v = big.cpu().numpy()
+    assert abs(v.mean()) < 5e-3 and abs(v.std() - 1) < 5e-3 and np.abs(v).max() < 7
+
+
+def test_philox_sampling_is_sharding_invariant_and_deterministic(dev):
+    """Rows depend on (seed, global row) only: an 8-row call equals two 4-row calls at row
+    offsets 0 and 4, and a repeat is bit-identical."""
+    from dynamics_aware_diffusion_amd import GuidedPolicy, _engine
+    diff = build("tiny", 20, "cosine", dev)
+    diff.sampler_rng, diff.seed = "philox", 4242
+    lib = _engine.load_library()
+    try:
+        lib.dad_debug_set_tile(1)                      # same tile => same summation order
+        pol = GuidedPolicy(diff, None)
+        cond = {0: torch.from_numpy(cases.loop_condition("inv", "tiny")).to(dev)}
+        full = pol.sample_loop(batch_size=8, conditions=cond)
+        again = pol.sample_loop(batch_size=8, conditions=cond)
+        lo = pol.sample_loop(batch_size=4, conditions=cond, row_offset=0)
+        hi = pol.sample_loop(batch_size=4, conditions=cond, row_offset=4)
+        torch.cuda.synchronize()
+        assert torch.equal(full, again)
+        assert torch.equal(full, torch.cat([lo, hi]))
+        diff.seed = 4243
+        other = pol.sample_loop(batch_size=8, conditions=cond)
+        assert not torch.equal(full, other)
+        # unconditional p_sample_loop takes the same route
+        a = diff.p_sample_loop((4, 32, 6), row_offset=4)
+        diff.seed = 4242
+        b = diff.p_sample_loop((8, 32, 6))
+        c = diff.p_sample_loop((4, 32, 6), row_offset=4)
+        assert torch.equal(b[4:], c) and not torch.equal(a, c)
+    finally:
+        lib.dad_debug_set_tile(-1)
+        diff.sampler_rng = "torch"
+
+
+def test_projection_inside_the_loop_opt_in(dev):
+    """README semantics x_{i-1} = project(denoise(x_i)): HIP loop vs the oracle loop with the
+    projection as post-step; and the shipped default (no projection) stays untouched."""
+    from dynamics_aware_diffusion_amd import DynamicsAwarePolicy
+    from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder
+    from tests.test_hip_parity import injected_noise
+    net, T, B = "tiny", 20, 5
+    diff = build(net, T, "cosine", dev)
+    A, Bm = oproj.double_integrator(0.1)
+    P = ProjectionMatrixBuilder(A, Bm, 4, 2).get_projection_matrix(32)
+    norm = cases.NormalizerStub(4, 2)
+    noise = cases.loop_noise("projloop", net, T, B)
+    cond = torch.from_numpy(cases.loop_condition("projloop", net))
+    stats = [torch.from_numpy(v) for v in (norm.obs_mean, norm.obs_std, norm.action_mean, norm.action_std)]
+    sched = orc.schedule_buffers("cosine", T)
+
+    def post(x, i):
+        a = oproj.projection_alpha("noise_schedule", 1.0, i, T, sched["betas"])
+        return oproj.apply_projection(x, P, a, 4, 4, *stats)
+
+    want_proj = orc.sample_loop(net_weights_torch(net), sched, torch.from_numpy(noise), T, {0: cond},
+                                post_step=post)
+    want_plain = orc.sample_loop(net_weights_torch(net), sched, torch.from_numpy(noise), T, {0: cond})
+    kw = dict(projection_matrix=P, normalizer=norm, state_dim=4, observation_dim=4, action_dim=2,
+              horizon=32, projection_schedule="noise_schedule", projection_strength=1.0)
+    for opt_in, want in ((True, want_proj), (False, want_plain)):
+        pol = DynamicsAwarePolicy(diff, project_during_sampling=opt_in, **kw)
+        with injected_noise(noise, dev):
+            got = pol.sample_loop(batch_size=B, conditions={0: cond.to(dev)})
+        torch.cuda.synchronize()
+        assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_LOOP, opt_in
+    assert max_abs(want_proj.numpy(), want_plain.numpy()) > 1e-3      # the projection matters
+
+
+def test_full_size_properties_pointmaze_b256(dev):
+    """BASELINE config 2 at full size (batch 256, T=100), through size-independent checks:
+    rows are independent of their batch (rows 0..3 of the 256-row run == a 4-row run),
+    inpainted step 0 is exact, x0-clamping keeps plans bounded, results are deterministic."""
+    from dynamics_aware_diffusion_amd import GuidedPolicy
+    net, T = "pointmaze", 100
+    diff = build(net, T, "cosine", dev)
+    diff.sampler_rng, diff.seed = "philox", 99
+    try:
+        pol = GuidedPolicy(diff, None)
+        c = cases.loop_condition("full", net)
+        cond = {0: torch.from_numpy(c).to(dev)}
+        big = pol.sample_loop(batch_size=256, conditions=cond)
+        big2 = pol.sample_loop(batch_size=256, conditions=cond)
+        small = pol.sample_loop(batch_size=4, conditions=cond)
+        torch.cuda.synchronize()
+        assert torch.equal(big, big2)
+        assert torch.isfinite(big).all()
+        assert np.array_equal(big[:, 0].cpu().numpy(), np.broadcast_to(c, (256, 6)))
+        assert float(big.abs().max()) <= 1.0 + 1e-3          # last step: sigma = 0, |x0| <= 1
+        # batch 4 and batch 256 may pick different tiles (summation order): fp32 tolerance
+        assert max_abs(big[:4].cpu().numpy(), small.cpu().numpy()) <= TOL_LOOP
+        # distinct rows are distinct plans
+        assert float((big[1:] - big[:-1]).abs().max()) > 1e-2
+    finally:
+        diff.sampler_rng = "torch"
+
+
+def test_engine_argument_errors(dev):
+    from dynamics_aware_diffusion_amd._engine import DadError
+    diff = build("tiny", 20, "cosine", dev)
+    eng = diff._engine(dev)
+    with pytest.raises(RuntimeError):
+        eng.unet_forward(torch.zeros(2, 16, 6, device=dev), 0)            # wrong horizon
+    with pytest.raises(RuntimeError):
+        eng.unet_forward(torch.zeros(2, 32, 6, device=dev).double(), 0)   # wrong dtype
+    with pytest.raises(DadError):
+        eng.unet_forward(torch.zeros(2, 32, 6, device=dev), 20)           # t outside schedule
+    with pytest.raises(RuntimeError):
+        eng.denoise_step(torch.zeros(2, 32, 6, device=dev), 0, cond0=torch.zeros(3, 6, device=dev))
+
+
+def test_weights_refresh_after_load_state_dict(dev):
+    """The packed engine copy follows the module's parameters (checkpoint reload)."""
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    from dynamics_aware_diffusion_amd.utils import synth
+    unet = TemporalUnet(6, dim=32, dim_mults=(1, 2, 4))
+    diff = GaussianDiffusion(unet, 32, 4, 2, n_timesteps=20).to(dev)
+    x = torch.from_numpy(synth.normal_like(64, "refresh.x", (3, 32, 6)))
+    for seed in (3, 8):
+        state = synth.synth_unet_state(6, 32, (1, 2, 4), seed=seed, affine_jitter=0.25)
+        w = {k: torch.from_numpy(v) for k, v in state.items()}
+        sd = diff.state_dict()
+        sd.update({"model." + k: v for k, v in w.items()})
+        diff.load_state_dict(sd)                       # reference checkpoint format
+        with torch.no_grad():
+            want = orc.unet_forward(w, x, torch.full((3,), 4, dtype=torch.long))
+        got = diff.model(x.to(dev), 4)
+        assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, seed

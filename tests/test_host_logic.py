@@ -1,0 +1,298 @@
+"""CPU tests (`-m "not gpu"`): the C-ABI library loads and exports what include/dad.h declares,
+and the host-side mirror of the reference API (schedules, state_dict schema, projector
+builder, planner glue, sharding) behaves like the reference.  No compute call needs a GPU."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.util import GOLDEN, golden, max_abs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------------- ABI
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "dad.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dad_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dynamics_aware_diffusion_amd import _engine
+    declared = _header_functions()
+    assert len(declared) >= 15
+    assert sorted(_engine.ABI) == declared, "ctypes table and include/dad.h disagree"
+    lib = _engine.load_library()                    # raises if the .so is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dad_version()
+
+
+def test_abi_rejects_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call, so it is checkable on CPU."""
+    import ctypes as C
+    from dynamics_aware_diffusion_amd import _engine
+    lib = _engine.load_library()
+    cfg = _engine.DadCfg()
+    cfg.transition_dim, cfg.dim, cfg.time_dim, cfg.n_levels = 6, 32, 32, 3
+    for i, ch in enumerate((32, 64, 128)):
+        cfg.channels[i] = ch
+    cfg.kernel_size, cfg.horizon, cfg.n_timesteps = 5, 32, 20
+    cfg.predict_epsilon = cfg.clip_denoised = 1
+    h = C.c_void_p()
+    assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == 0
+    n = C.c_size_t()
+    assert lib.dad_workspace_bytes(h, 4, C.byref(n)) == 0 and n.value > 0
+    # unknown key / wrong shape
+    buf = (C.c_float * 8)()
+    shape = (C.c_int64 * 1)(8)
+    assert lib.dad_model_load_weight(h, b"no.such.key", buf, shape, 1) == -3
+    assert b"no.such.key" in lib.dad_last_error()
+    assert lib.dad_model_load_weight(h, b"final_conv.1.bias", buf, shape, 1) == -3   # 6 expected
+    # step before finalize
+    assert lib.dad_unet_forward(h, None, 0, None, 1, None, 0, None) == -2
+    lib.dad_model_destroy(h)
+    # unsupported architectures are refused with a message, not a crash
+    cfg.kernel_size = 3
+    assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == -1
+    cfg.kernel_size, cfg.horizon = 5, 8                 # 8 / 2^2 = 2 < 4
+    assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == -1
+    cfg.horizon = 32
+    cfg.channels[1] = 48                                # not a multiple of 32
+    assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from dynamics_aware_diffusion_amd import _engine
+    monkeypatch.setattr(_engine, "_lib", None)
+    monkeypatch.setattr(_engine, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _engine.load_library()
+
+
+# ------------------------------------------------------------------------------ schedules
+def test_schedule_buffers_match_reference_bitwise():
+    from dynamics_aware_diffusion_amd.models.diffusion import make_schedule
+    g = golden("schedules")
+    for name, T in cases.SCHEDULE_CASES:
+        bufs = make_schedule(name, T)
+        assert list(bufs) == [k.split(".", 1)[1] for k in g.files if k.startswith(f"{name}_{T}.")]
+        for k, v in bufs.items():
+            assert np.array_equal(v.numpy(), g[f"{name}_{T}.{k}"]), (name, T, k)
+    with pytest.raises(ValueError, match="Unknown beta schedule"):
+        make_schedule("sigmoid", 10)
+
+
+def test_state_dict_schema_matches_reference():
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    want = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    for net in ("tiny", "tiny4", "pointmaze"):
+        od, ad, td, dim, mults = cases.net_dims(net)
+        diff = GaussianDiffusion(TemporalUnet(td, dim=dim, dim_mults=mults), cases.H, od, ad,
+                                 n_timesteps=cases.NETS[net][4])
+        sd = diff.state_dict()
+        ref = dict(want[net]["buffers"], **want[net]["model"])
+        assert list(sd) == want[net]["order"], net              # same keys, same order
+        for k, v in sd.items():
+            assert list(v.shape) == ref[k], (net, k)
+    # big nets: shapes only (no allocation)
+    from dynamics_aware_diffusion_amd.utils.synth import unet_param_shapes
+    for net in ("halfcheetah", "door"):
+        od, ad, td, dim, mults = cases.net_dims(net)
+        shapes = unet_param_shapes(td, dim, mults, prefix="model.")
+        assert {k: list(v) for k, v in shapes.items()} == want[net]["model"]
+
+
+def test_diffusion_attributes_and_errors():
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    unet = TemporalUnet(6, dim=32, dim_mults=(1, 2))
+    d = GaussianDiffusion(unet, 32, 4, 2, n_timesteps=50, beta_schedule="linear")
+    assert (d.horizon, d.observation_dim, d.action_dim, d.transition_dim) == (32, 4, 2, 6)
+    assert d.n_timesteps == 50 and d.betas.shape == (50,) and d.beta_schedule == "linear"
+    d.n_timesteps = 10                                   # evaluate.py:352 mutates it
+    with pytest.raises(ValueError, match="Unknown loss type"):
+        GaussianDiffusion(unet, 32, 4, 2, loss_type="huber")
+    with pytest.raises(ValueError, match="Unknown beta schedule"):
+        GaussianDiffusion(unet, 32, 4, 2, beta_schedule="exp")
+    # closed forms stay plain torch and work on CPU (training-side helpers)
+    x0 = torch.randn(3, 32, 6)
+    t = torch.tensor([0, 5, 49])
+    z = torch.randn_like(x0)
+    xt = d.q_sample(x0, t, z)
+    assert torch.allclose(d.predict_start_from_noise(xt, t, z), x0, atol=1e-4)
+    mean, logvar = d.q_posterior(x0, xt, t)
+    assert mean.shape == x0.shape and logvar.shape == (3, 1, 1)
+    with pytest.raises(RuntimeError):                    # gather out of range, like the reference
+        d.q_sample(x0, torch.tensor([0, 5, 50]), z)
+    with pytest.raises(NotImplementedError):
+        d.loss(x0)
+
+
+# ------------------------------------------------------------------------------ projection
+def test_projection_builder_matches_reference():
+    from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder
+    from oracle.projection import double_integrator, lifted_map
+    g = golden("projection")
+    for case, dt, Hh in cases.PROJ_MATRIX_CASES:
+        A, B = double_integrator(dt)
+        b = ProjectionMatrixBuilder(A, B, 4, 2)
+        assert np.allclose(b._build_F_matrix(Hh), lifted_map(A, B, Hh), atol=0, rtol=0)
+        P = b.get_projection_matrix(Hh)
+        assert P.dtype == torch.float32 and P.shape == ((Hh + 1) * 4 + Hh * 2,) * 2
+        assert max_abs(P.numpy(), g[case]) <= 1e-6
+        assert b.verify_projection(P)
+        assert np.linalg.matrix_rank(P.double().numpy(), tol=1e-6) == 4 + Hh * 2
+    with pytest.raises(AssertionError):
+        ProjectionMatrixBuilder(np.eye(3), np.zeros((4, 2)), 4, 2)
+
+
+# ---------------------------------------------------------------------------- planner glue
+class _FakeDiffusion(torch.nn.Module):
+    horizon, observation_dim, action_dim, transition_dim, n_timesteps = 32, 4, 2, 6, 20
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("betas", torch.linspace(1e-4, 0.02, 20))
+
+
+def test_action_buffer_and_observation_glue():
+    from dynamics_aware_diffusion_amd import DynamicsAwarePolicy, GuidedPolicy, MPCPolicy
+    norm = cases.NormalizerStub(4, 2)
+    diff = _FakeDiffusion()
+    traj = torch.from_numpy(np.arange(32 * 6, dtype=np.float32).reshape(1, 32, 6))
+    for ah, expect in ((1, 2), (8, 9), (32, 32), (100, 32)):      # min(a + 1, H) entries
+        pol = GuidedPolicy(diff, norm, action_horizon=ah)
+        pol._fill_action_buffer(traj)
+        assert len(pol.action_buffer) == expect
+        want0 = norm.unnormalize_actions(traj[0, 0, 4:6].numpy().reshape(1, -1)).flatten()
+        assert np.array_equal(pol.action_buffer[0], want0)        # starts at horizon step 0
+        first = pol.get_action(np.zeros(4))                       # served from the buffer
+        assert np.array_equal(first, want0) and len(pol.action_buffer) == expect - 1
+    assert GuidedPolicy(diff, norm).action_horizon == 1
+    assert MPCPolicy(diff, norm).action_horizon == 8
+    assert DynamicsAwarePolicy(diff, normalizer=norm, horizon=32).action_horizon == 32
+    pol = GuidedPolicy(diff, norm)
+    obs = {"observation": np.arange(4.0), "desired_goal": np.ones(2), "achieved_goal": np.zeros(2)}
+    assert pol._process_observation(obs).shape == (1, 4)           # state-only model
+    pol6 = GuidedPolicy(diff, cases.NormalizerStub(6, 2))
+    assert pol6._process_observation(obs).shape == (1, 6)          # goal-conditioned model
+    assert pol._process_observation({"achieved_goal": np.ones(3)}).shape == (1, 3)
+    assert pol._process_observation([1.0, 2.0, 3.0, 4.0]).shape == (1, 4)
+
+
+def test_projection_alpha_schedules_match_reference():
+    from dynamics_aware_diffusion_amd import DynamicsAwarePolicy
+    from oracle.denoiser import schedule_buffers
+    g = golden("projection")
+    diff = _FakeDiffusion()
+    diff.n_timesteps = 100
+    diff.betas = schedule_buffers("cosine", 100)["betas"]
+    for sched in cases.PROJ_SCHEDULES:
+        pol = DynamicsAwarePolicy(diff, normalizer=cases.NormalizerStub(4, 2), horizon=32,
+                                  projection_schedule=sched, projection_strength=cases.PROJ_STRENGTH)
+        for t in cases.PROJ_T:
+            assert abs(pol._get_projection_alpha(t) - float(g[f"alpha_{sched}_{t}"])) <= 1e-12
+    # no projector or no normaliser: identity, as the reference (policies.py:422-423)
+    pol = DynamicsAwarePolicy(diff, projection_matrix=None, normalizer=None, horizon=32)
+    x = torch.zeros(2, 32, 6)
+    assert pol.apply_projection(x, 3) is x
+
+
+def test_sampler_refuses_cpu_tensors():
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, GuidedPolicy, TemporalUnet
+    unet = TemporalUnet(6, dim=32, dim_mults=(1, 2))
+    diff = GaussianDiffusion(unet, 32, 4, 2, n_timesteps=10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        unet(torch.zeros(1, 32, 6), torch.zeros(1, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        diff.p_sample_loop((1, 32, 6))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GuidedPolicy(diff, None).sample_loop(batch_size=1)
+    with pytest.raises(NotImplementedError):             # one timestep per call
+        TemporalUnet.shared_timestep(torch.tensor([1, 2]))
+
+
+# -------------------------------------------------------------------------------- Philox
+def test_philox_known_answers_and_moments():
+    from oracle import philox
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]          # Random123 kat_vectors
+    for ctr, key, want in kat:
+        got = philox.philox4x32_10(np.array(ctr, np.uint32), np.array(key, np.uint32))
+        assert got.tolist() == list(want)
+    z = philox.normal(np.arange(400_000, dtype=np.uint64), draw=3, seed=12345)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and np.isfinite(z).all()
+    assert not np.array_equal(z[:1000], philox.normal(np.arange(1000, dtype=np.uint64), 4, 12345))
+
+
+# ------------------------------------------------------------------------------- sharding
+def test_shard_ranges_cover_the_batch():
+    from dynamics_aware_diffusion_amd.utils.sharding import shard_range
+    for total in (0, 1, 7, 256, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert sum(c for _, c in spans) == total
+            pos = 0
+            for start, count in spans:
+                assert start == pos
+                pos += count
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from dynamics_aware_diffusion_amd.utils import synth
+from dynamics_aware_diffusion_amd.utils.sharding import gather_plans, sample_sharded, shard_range
+rank, world, total = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+full = torch.from_numpy(synth.normal_like(9, "shard.plans", (total, 32, 6)))
+
+class StubPolicy:                       # rows are a pure function of the GLOBAL row index
+    def sample_loop(self, batch_size, conditions=None, row_offset=0):
+        out = full[row_offset:row_offset + batch_size].clone()
+        if conditions is not None:
+            out[:, 0] = conditions[0]
+        return out
+
+start, count = shard_range(total, world, rank)
+got = gather_plans(full[start:start + count].clone(), total)
+assert torch.equal(got, full), "gather order"
+cond = torch.from_numpy(synth.normal_like(9, "shard.cond", (total, 6)))
+got2 = sample_sharded(StubPolicy(), total, {0: cond})
+want2 = full.clone(); want2[:, 0] = cond
+assert torch.equal(got2, want2), "per-row conditions"
+got3 = sample_sharded(StubPolicy(), total, {0: cond[:1]})
+want3 = full.clone(); want3[:, 0] = cond[:1]
+assert torch.equal(got3, want3), "broadcast condition"
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_two_rank_gather_over_gloo(tmp_path, total):
+    """world_size-2 CPU rehearsal of the multi-GPU path: shard -> sample -> gather."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + total + os.getpid() % 200),
+               WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(total)],
+                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\n{out}"
+        assert f"rank {r} ok" in out
