@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs of profiles/collect.sh into the small files committed under
+profiles/:  <tag>_kernel_stats.csv (rocprofv3 --stats table), <tag>_summary.json (per-kernel
+averages, HBM traffic per launch from the PMC passes with the gfx950 corrections of
+MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request on wide reads, so it is doubled;
+both counters are in KiB) and traffic.json (what bench.py reports as roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+stats = one("trace/**/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
+
+summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"}
+trace = one("trace/**/*_kernel_trace.csv")
+if trace:
+    rows = [r for r in csv.DictReader(open(trace)) if "dad::" in r["Kernel_Name"]]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    summary["kernels_us"] = {k: {"calls": n, "total_us": t, "avg_us": t / n} for k, (n, t) in agg.items()}
+    conv = [(n, t) for k, (n, t) in agg.items() if "conv_gemm_f32" in k]
+    summary["conv_gemm_all_variants"] = {"calls": sum(n for n, _ in conv),
+                                         "total_us": sum(t for _, t in conv),
+                                         "avg_us": sum(t for _, t in conv) / max(1, sum(n for n, _ in conv))}
+
+
+def pmc(dirname, counter):
+    f = one(f"{dirname}/**/*_counter_collection.csv")
+    if not f:
+        return None
+    tot, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if "conv_gemm_f32" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            tot["conv"] += float(r["Counter_Value"])
+            n["conv"] += 1
+    return (tot["conv"], n["conv"]) if n["conv"] else None
+
+
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+if fetch and write:
+    per_launch = (2.0 * fetch[0] / fetch[1] + write[0] / write[1]) * 1024.0
+    summary["hbm_traffic"] = {
+        "FETCH_SIZE_KiB_per_launch_raw": fetch[0] / fetch[1],
+        "WRITE_SIZE_KiB_per_launch": write[0] / write[1],
+        "bytes_per_conv_launch": per_launch,
+        "note": "FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request); includes Infinity-Cache hits",
+    }
+    tpath = os.path.join(here, "traffic.json")
+    cur = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    cur["pointmaze_b256"] = per_launch
+    json.dump(cur, open(tpath, "w"), indent=1)
+
+sq = one("pmc_sq/**/*_counter_collection.csv")
+if sq:
+    tot = collections.defaultdict(float)
+    for r in csv.DictReader(open(sq)):
+        if "conv_gemm_f32" in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+    summary["sq_counters_conv_total"] = dict(tot)
+    if tot.get("SQ_WAVE_CYCLES"):
+        wc = tot["SQ_WAVE_CYCLES"]
+        summary["sq_ratios"] = {k: tot[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in tot}
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj) and os.path.getsize(bj):
+    summary["bench_line"] = json.loads(open(bj).read().strip().splitlines()[-1])
+json.dump(summary, open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1)
+print("wrote", f"{tag}_summary.json")
