@@ -201,11 +201,12 @@ class HipEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def workspace(self, batch: int) -> torch.Tensor:
+        """Device scratch for `batch` rows (activations + split-K slabs); grown on demand."""
+        n = C.c_size_t()
+        _check(self.lib, self.lib.dad_workspace_bytes(self._h, batch, C.byref(n)))
         ws = self._ws.get(batch)
-        if ws is None:
-            n = C.c_size_t()
-            _check(self.lib, self.lib.dad_workspace_bytes(self._h, batch, C.byref(n)))
-            ws = torch.empty(max(n.value, 4) // 4, dtype=torch.float32, device=self.device)
+        if ws is None or ws.numel() * 4 < n.value:
+            ws = torch.empty(max(n.value, 4) // 4 + 4, dtype=torch.float32, device=self.device)
             self._ws[batch] = ws
         return ws
 

@@ -50,6 +50,11 @@ struct ConvParams {
     int32_t lshift;      // log2(Lout)
     int32_t interleave;  // transposed-conv store: col m<M/2 -> row 2l, m>=M/2 -> row 2l+1
     int32_t ntiles_n;    // number of N tiles (for the XCD-aware tile order)
+    // grid-level split-K (few tiles: small batches, the deepest levels of wide nets)
+    int32_t kslices;     // blocks per output tile (1 = off)
+    int32_t chunks_per_slice;
+    float* slab;         // [tiles][kslices][BN*BM] fp32 partial tiles (workspace)
+    unsigned* counters;  // [tiles] arrival tickets, zero between launches
 };
 
 __device__ __forceinline__ float mish_f32(float y) {
@@ -85,7 +90,7 @@ __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int ta
                                                   int Lout, int SK) {
     const size_t kp = KC + 4;
     const size_t stage = ((size_t)conv_xrows(BN, Lin, Lout, taps) + (size_t)taps * BM) * kp;
-    const size_t epi = (size_t)SK * BN * (BM + 4) + 32;
+    const size_t epi = (size_t)SK * BN * (BM + 4) + 64;
     const size_t k = 2 * stage;
     return k > epi ? k : epi;
 }
@@ -130,6 +135,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int kb = tile % p.kslices;             // this block's K slice of its output tile
+    tile /= p.kslices;                           // slices of one tile are adjacent: same XCD
     const int mt = tile / p.ntiles_n;
     const int nt = tile - mt * p.ntiles_n;
 
@@ -158,10 +165,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
 
     const int cin = p.cin0 + p.cin1;
+    const int c_begin = kb * p.chunks_per_slice;
 #ifdef DAD_ABLATE_NOLOOP
-    const int nchunks = 1;
+    const int nchunks = c_begin + 1;
 #else
-    const int nchunks = p.cin_pad / KC;
+    const int nchunks = min(p.cin_pad / KC, c_begin + p.chunks_per_slice);   // one past the last
 #endif
 
     // ---- staging: global -> registers (prefetch) -> LDS ---------------------------------
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * 8]);
     };
 
-    load_stage(0);                         // first global loads fly while LDS is being zeroed
+    load_stage(c_begin);                   // first global loads fly while LDS is being zeroed
     // zero both X stages once: halo rows (and rows of samples that do not exist) stay zero,
     // staging only ever writes real positions.  (XF is a multiple of 4 floats.)
     for (int i = tid * 4; i < XF; i += NT * 4) {
@@ -279,12 +287,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     }
     __syncthreads();                       // zero fill done before real rows land
     store_stage(0);
-    if (nchunks > 1) load_stage(1);
+    if (c_begin + 1 < nchunks) load_stage(c_begin + 1);
     __syncthreads();
     float4 ca = frag_a(0, 0), cb = frag_b(0, 0);
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int cur = ch & 1;
+    for (int ch = c_begin; ch < nchunks; ++ch) {
+        const int cur = (ch - c_begin) & 1;
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
             float4 na = ca, nb = cb;
@@ -395,8 +403,54 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             const float4 u = *reinterpret_cast<const float4*>(q + c * ECOPY);
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
-        y[k][0] = v.x + bias4[k].x; y[k][1] = v.y + bias4[k].y;
-        y[k][2] = v.z + bias4[k].z; y[k][3] = v.w + bias4[k].w;
+        y[k][0] = v.x; y[k][1] = v.y; y[k][2] = v.z; y[k][3] = v.w;
+    }
+
+    if (p.kslices > 1) {
+        // Grid-level split-K: every block of the tile parks its partial tile in HBM; the block
+        // that draws the last ticket adds all of them in slice order (bit-reproducible whichever
+        // block is last) and goes on to the epilogue alone.  Placement-independent hand-off:
+        // plain stores -> every wave drains -> barrier -> one agent-scope release -> ticket;
+        // the reducer takes one agent-scope acquire before any slab load (cdna guide, G16).
+        const int KS = p.kslices;
+        float* mine = p.slab + ((long)tile * KS + kb) * (BN * BM);
+#pragma unroll
+        for (int k = 0; k < F4PL; ++k)
+            *reinterpret_cast<float4*>(mine + erow[k] * BM + ecol[k]) =
+                make_float4(y[k][0], y[k][1], y[k][2], y[k][3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(smem + SK * ECOPY + 32);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = ticket == (unsigned)(KS - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        const float* base = p.slab + (long)tile * KS * (BN * BM);
+#pragma unroll
+        for (int k = 0; k < F4PL; ++k) {
+            const float* q = base + erow[k] * BM + ecol[k];
+            float4 v = *reinterpret_cast<const float4*>(q);
+            for (int c = 1; c < KS; ++c) {
+                const float4 u = *reinterpret_cast<const float4*>(q + (long)c * (BN * BM));
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            y[k][0] = v.x; y[k][1] = v.y; y[k][2] = v.z; y[k][3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < F4PL; ++k) {
+        y[k][0] += bias4[k].x; y[k][1] += bias4[k].y; y[k][2] += bias4[k].z; y[k][3] += bias4[k].w;
     }
 
     if (has_gn) {

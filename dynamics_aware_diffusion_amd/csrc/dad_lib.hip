@@ -21,6 +21,7 @@ namespace {
 
 thread_local char g_err[1024] = "";
 int g_force_tile = -1;      // dad_debug_set_tile: tuning / test hook
+bool g_split_enabled = true;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -80,6 +81,7 @@ struct Plan {
     int temb_width = 0;       // sum of C_out over residual blocks
 };
 
+constexpr int kMaxSplitTiles = 4096;
 struct TileCfg { int BM, BN, SK, KC; };
 // Block tile (BM channels x BN positions), SK-way intra-block split-K, K chunk.  Every
 // configuration runs 8 waves per block except the last (4 waves, two blocks per CU).
@@ -118,6 +120,7 @@ struct dad_model {
     float* d_final_w = nullptr;       // [td][dim]
     float* d_final_b = nullptr;
     uint64_t* d_rng = nullptr;
+    unsigned* d_counters = nullptr;   // split-K arrival tickets (zero between launches)
     std::vector<void*> owned;         // every hipMalloc to free
     // profiling
     bool profile = false;
@@ -363,6 +366,7 @@ void free_device(dad_model* m) {
     m->d_temb_table = nullptr;
     m->d_final_w = m->d_final_b = nullptr;
     m->d_rng = nullptr;
+    m->d_counters = nullptr;
     for (auto& op : m->plan.convs) op.d_w = op.d_bias = op.d_gamma = op.d_beta = nullptr;
 }
 
@@ -389,7 +393,7 @@ int launch_conv_t(ConvParams& p, hipStream_t st) {
     const size_t lds = dad::conv_lds_floats(T::BM, T::BN, T::KC, TAPS, p.Lin, p.Lout, T::SK) * sizeof(float);
     const int spt = T::BN / p.Lout;
     p.ntiles_n = (p.B + spt - 1) / spt;
-    const int nblocks = p.ntiles_n * (p.M / T::BM);
+    const int nblocks = p.ntiles_n * (p.M / T::BM) * p.kslices;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (T::BM / 32) * (T::BN / 32) * T::SK), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;
@@ -480,6 +484,38 @@ int choose_tile(const ConvOp& op, int batch) {
     return -1;
 }
 
+// Grid-level split-K: when a layer has too few output tiles to cover the chip (small batches;
+// the deepest levels of the wide nets), several blocks share a tile and split its K chunks.
+struct SplitPlan { int kslices, chunks_per_slice; long slab_floats; };
+SplitPlan plan_split(const ConvOp& op, int cfg, int batch) {
+    const TileCfg& t = kTiles[cfg];
+    const int spt = t.BN / op.Lout;
+    const long tiles = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
+    const int nchunks = op.cin_pad / t.KC;
+    SplitPlan sp{1, nchunks, 0};
+    if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
+    int want = (int)((256 + tiles - 1) / tiles);
+    if (want > nchunks) want = nchunks;
+    if (want < 2) return sp;
+    sp.chunks_per_slice = (nchunks + want - 1) / want;
+    sp.kslices = (nchunks + sp.chunks_per_slice - 1) / sp.chunks_per_slice;
+    sp.slab_floats = tiles * sp.kslices * (long)t.BN * t.BM;
+    return sp;
+}
+
+int choose_tile(const ConvOp& op, int batch);
+
+// floats of split-K scratch a batch needs (max over layers)
+long slab_floats_for(const dad_model* m, int batch) {
+    long best = 0;
+    for (const ConvOp& op : m->plan.convs) {
+        const int cfg = choose_tile(op, batch);
+        if (cfg < 0) continue;
+        best = std::max(best, plan_split(op, cfg, batch).slab_floats);
+    }
+    return best;
+}
+
 int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int batch, int t,
              hipStream_t st) {
     auto buf = [&](int id) -> float* {
@@ -500,6 +536,11 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     if (cfg < 0)
         return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
                     op.name.c_str(), op.M, op.cout / 8, op.Lout);
+    const SplitPlan sp = g_split_enabled ? plan_split(op, cfg, batch) : SplitPlan{1, op.cin_pad / kTiles[cfg].KC, 0};
+    p.kslices = sp.kslices;
+    p.chunks_per_slice = sp.chunks_per_slice;
+    p.slab = ws + m->plan.floats_per_sample * (long)batch;     // scratch behind the activations
+    p.counters = m->d_counters;
     int rc;
     switch (cfg) {
         case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, st); break;
@@ -521,7 +562,7 @@ int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
     if (t < 0 || t >= m->cfg.n_timesteps)
         return fail(DAD_E_RANGE, "index %d is out of bounds for the schedule of size %d", t,
                     m->cfg.n_timesteps);
-    const size_t need = (size_t)m->plan.floats_per_sample * batch * sizeof(float);
+    const size_t need = ((size_t)m->plan.floats_per_sample * batch + (size_t)slab_floats_for(m, batch)) * sizeof(float);
     if (ws_bytes < need)
         return fail(DAD_E_WORKSPACE, "workspace has %zu bytes, batch %d needs %zu", ws_bytes, batch,
                     need);
@@ -764,6 +805,11 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     HIP_TRY(hipMalloc(&rng, 64));
     m->owned.push_back(rng);
     m->d_rng = (uint64_t*)rng;
+    void* cnt = nullptr;
+    HIP_TRY(hipMalloc(&cnt, kMaxSplitTiles * sizeof(unsigned)));
+    m->owned.push_back(cnt);
+    HIP_TRY(hipMemsetAsync(cnt, 0, kMaxSplitTiles * sizeof(unsigned), st));
+    m->d_counters = (unsigned*)cnt;
     HIP_TRY(hipStreamSynchronize(st));
     m->raw.clear();
     m->finalized = true;
@@ -772,7 +818,7 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
 
 int dad_workspace_bytes(const dad_model* m, int32_t batch, size_t* bytes) {
     if (!m || !bytes || batch <= 0) return fail(DAD_E_INVALID, "bad argument");
-    *bytes = (size_t)m->plan.floats_per_sample * (size_t)batch * sizeof(float);
+    *bytes = ((size_t)m->plan.floats_per_sample * (size_t)batch + (size_t)slab_floats_for(m, batch)) * sizeof(float);
     return DAD_OK;
 }
 
@@ -877,7 +923,9 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, u
 }
 
 int dad_debug_set_tile(int32_t cfg) {
-    g_force_tile = cfg;
+    // cfg >= 100: same, with grid-level split-K disabled (cfg - 100 is the tile, 99 = heuristic)
+    g_split_enabled = cfg < 99;
+    g_force_tile = cfg >= 99 ? cfg - 100 : cfg;
     return DAD_OK;
 }
 

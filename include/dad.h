@@ -158,8 +158,9 @@ int dad_profile_enable(dad_model* m, int32_t on);
 int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops);
 
 /* Test / tuning hook: force conv tile configuration `cfg` (0..7, see kTiles in
- * csrc/dad_lib.hip) wherever it is valid for a layer; -1 restores the heuristic.  Results
- * do not depend on the tile beyond fp32 summation order. */
+ * csrc/dad_lib.hip) wherever it is valid for a layer; -1 restores the heuristic; 100+cfg
+ * (99 = heuristic tile) additionally disables grid-level split-K.  Results do not depend on
+ * these choices beyond fp32 summation order. */
 int dad_debug_set_tile(int32_t cfg);
 
 #ifdef __cplusplus

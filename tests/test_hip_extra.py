@@ -45,6 +45,30 @@ def test_every_tile_variant_matches_oracle(tile, dev):
         lib.dad_debug_set_tile(-1)
 
 
+def test_grid_split_k_is_exact_to_rounding_and_deterministic(dev):
+    """Small batches split K over several blocks per tile (last-arriver reduction in slice
+    order): same answer as the unsplit kernel to fp32 rounding, bit-identical run to run."""
+    from dynamics_aware_diffusion_amd import _engine
+    from dynamics_aware_diffusion_amd.utils import synth
+    lib = _engine.load_library()
+    diff = build("pointmaze", 100, "cosine", dev)
+    for B in (1, 3, 8):
+        x = torch.from_numpy(synth.normal_like(65, f"splitk.{B}", (B, 32, 6)))
+        want = _oracle_eps("pointmaze", x, 42).numpy()
+        xd = x.to(dev)
+        try:
+            lib.dad_debug_set_tile(-1)
+            a = diff.model(xd, 42).cpu().numpy()
+            b = diff.model(xd, 42).cpu().numpy()
+            lib.dad_debug_set_tile(99)                   # heuristic tiles, split-K off
+            c = diff.model(xd, 42).cpu().numpy()
+        finally:
+            lib.dad_debug_set_tile(-1)
+        assert np.array_equal(a, b)
+        assert max_abs(a, want) <= TOL_STEP and max_abs(c, want) <= TOL_STEP
+        assert max_abs(a, c) <= 1e-5
+
+
 def test_wide_group_tiles_on_big_architectures(dev):
     """HalfCheetah / Door exercise the 128- and 256-channel GroupNorm tiles (cfg 2 and 3)."""
     for name, net, B, t in cases.FORWARD_CASES[3:]:
