@@ -29,6 +29,17 @@
 
 namespace dad {
 
+#ifdef DAD_STAMPS
+#define DAD_STAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DAD_STAMP(i) do {} while (0)
+#endif
+#ifdef DAD_STAMPS
+#define DAD_CLOCK(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DAD_CLOCK(i) do {} while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvParams {
@@ -48,6 +59,7 @@ struct ConvParams {
     int32_t B;           // batch rows in this call
     int32_t Lin, Lout;   // per-sample input / output length of the GEMM
     int32_t lshift;      // log2(Lout)
+    int32_t lshift_in;   // log2(Lin)
     int32_t interleave;  // transposed-conv store: col m<M/2 -> row 2l, m>=M/2 -> row 2l+1
     int32_t ntiles_n;    // number of N tiles (for the XCD-aware tile order)
     // grid-level split-K (few tiles: small batches, the deepest levels of wide nets)
@@ -55,6 +67,9 @@ struct ConvParams {
     int32_t chunks_per_slice;
     float* slab;         // [tiles][kslices][BN*BM] fp32 partial tiles (workspace)
     unsigned* counters;  // [tiles] arrival tickets, zero between launches
+#ifdef DAD_STAMPS
+    unsigned long long* stamps;   // diagnostic build only: [4096][8] realtime stamps per block
+#endif
 };
 
 __device__ __forceinline__ float mish_f32(float y) {
@@ -79,6 +94,24 @@ __device__ __forceinline__ float mish_fast_f32(float y) {
     const float n = __builtin_amdgcn_exp2f(t) * (1.0f + 0.693147180559945f * tl);
     const float w = n * (n + 2.0f);
     return y * (w * __builtin_amdgcn_rcpf(w + 2.0f));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
+                                                                 0xF, 0xF, true));
+}
+// After the in-row reduction every 16-lane row holds one value; rows are combined through
+// v_readlane (scalar broadcast) — four reads, no LDS, fixed order.
+__device__ __forceinline__ float rows_sum(float v, int width, int lane) {
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    const float lo = r0 + r1, hi = r2 + r3;
+    if (width >= 64) return lo + hi;
+    return lane < 32 ? lo : hi;
 }
 
 // Rows of the X stage: every sample of the tile with its zero halo.
@@ -115,6 +148,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     if (p.B > 0) return;
 #endif
 
+    DAD_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -169,7 +203,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #ifdef DAD_ABLATE_NOLOOP
     const int nchunks = c_begin + 1;
 #else
-    const int nchunks = min(p.cin_pad / KC, c_begin + p.chunks_per_slice);   // one past the last
+    // chunks that hold real channels (cin_pad may add all-zero chunks; they are never visited)
+    const int nchunks = min((p.cin0 + p.cin1 + KC - 1) / KC, c_begin + p.chunks_per_slice);   // one past the last
 #endif
 
     // ---- staging: global -> registers (prefetch) -> LDS ---------------------------------
@@ -201,14 +236,17 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int e = tid + i * NT;
         const int row = e / KQ;                             // s*Lin + l
         const int q = e - row * KQ;
-        const int s = row / Lin;
-        const int l = row - s * Lin;
+        const int s = row >> p.lshift_in;                   // Lin is a power of two
+        const int l = row - (s << p.lshift_in);
         const bool ok = e < xrows_real * KQ && s < nvalid;
         x_grow[i] = ok ? s0 * Lin + row : -1;
         x_q4[i] = q * 4;
         x_loff[i] = e < xrows_real * KQ ? (s * SEG + PAD + l) * KP + q * 4 : -1;
     }
     const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
+    // RAGGED = false promises (host-checked) that every K chunk lies inside one concat source and
+    // below cin, with 16-byte aligned channel quads: the X loads use one base pointer per chunk.
+    // RAGGED = true is the general path: first layer (cin = transition_dim), narrow nets.
 
     auto load_stage = [&](int chunk) {
         const float* wsrc = p.w + chunk * w_chunk_stride;
@@ -220,20 +258,34 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             wreg[i] = v;
         }
         const int c0 = chunk * KC;
-        const bool second = c0 >= p.cin0;
-        const float* xsrc = second ? p.src1 : p.src0;
-        const int cs = second ? p.cin1 : p.cin0;          // row stride of the source
-        const int cb = second ? c0 - p.cin0 : c0;
+        if constexpr (!RAGGED) {
+            // whole chunk inside one source and inside cin: one pointer per chunk
+            const bool second = c0 >= p.cin0;
+            const float* xsrc = second ? p.src1 : p.src0;
+            const int cs = second ? p.cin1 : p.cin0;      // row stride of the source
+            const int cb = second ? c0 - p.cin0 : c0;
+#pragma unroll
+            for (int i = 0; i < X_PER_T; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (x_grow[i] >= 0)
+                    v = *reinterpret_cast<const float4*>(xsrc + (long)x_grow[i] * cs + cb + x_q4[i]);
+                xreg[i] = v;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < X_PER_T; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x_grow[i] >= 0) {
-                const int cc = cb + x_q4[i];
-                const float* g = xsrc + (long)x_grow[i] * cs + cc;
-                if (!RAGGED) {
+            const int cc = c0 + x_q4[i];                  // first channel of this float4
+            if (x_grow[i] >= 0 && cc < cin) {             // beyond cin: zero padding of the chunk
+                // virtual concat: channels [0, cin0) come from src0, the rest from src1
+                const bool second = cc >= p.cin0;
+                const int cs = second ? p.cin1 : p.cin0;  // row stride of that source
+                const int cl = second ? cc - p.cin0 : cc;
+                const float* g = (second ? p.src1 : p.src0) + (long)x_grow[i] * cs + cl;
+                const int left = cs - cl;                 // channels remaining in this source
+                if ((cs & 3) == 0) {
                     v = *reinterpret_cast<const float4*>(g);
                 } else {                                  // first layer: cin = transition_dim
-                    const int left = cs - cc;             // channels remaining in this source
                     if (left > 0) v.x = g[0];
                     if (left > 1) v.y = g[1];
                     if (left > 2) v.z = g[2];
@@ -241,6 +293,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
                 }
             }
             xreg[i] = v;
+        }
         }
     };
     auto store_stage = [&](int stage) {
@@ -253,7 +306,6 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         for (int i = 0; i < X_PER_T; ++i)
             if (x_loff[i] >= 0) *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = xreg[i];
     };
-    (void)cin;
 
     // ---- main loop -------------------------------------------------------------------------
     // Software pipeline (explicit, the compiler does not build it):
@@ -278,6 +330,72 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * 8]);
     };
 
+    // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
+    // After the LDS exchange each thread owns F4PL float4 (4 channels x 1 position) of one
+    // (GroupNorm group, sample) pair; lanes of a pair are contiguous.  Without GroupNorm the
+    // mapping is plain row-major.
+    constexpr int ES = BM + 4;
+    constexpr int ECOPY = BN * ES;
+    constexpr int F4PL = (BN * BM / 4) / NT;           // float4 per thread
+    static_assert(F4PL >= 1 && (BN * BM / 4) % NT == 0, "epilogue mapping");
+#ifdef DAD_ABLATE_GN
+    const bool has_gn = false;
+#else
+    const bool has_gn = p.gamma != nullptr;
+#endif
+    const int cpg = has_gn ? p.cpg : BM;
+    const int cq = cpg >> 2;                           // float4 per row of a pair
+    const int cnt4 = has_gn ? (Lout * cq) : (BN * cq); // float4 per pair
+    static_assert((F4PL & (F4PL - 1)) == 0, "F4PL is a power of two");
+    const int lpp = cnt4 >> (F4PL == 1 ? 0 : F4PL == 2 ? 1 : F4PL == 4 ? 2 : 3);                       // lanes per pair (power of two >= 1)
+    // every quantity here is a power of two: shifts, not divisions (this runs before the first
+    // global load can be issued)
+    const int lpp_sh = 31 - __clz(lpp);
+    const int cq_sh = 31 - __clz(cq);
+    const int gpt_sh = 31 - __clz(BM) - (31 - __clz(cpg));
+    const int pr = tid >> lpp_sh;
+    const int lp = tid & (lpp - 1);
+    const int ps = has_gn ? pr >> gpt_sh : 0;          // sample of the pair
+    const int pg = has_gn ? pr & ((1 << gpt_sh) - 1) : 0;   // group of the pair
+    int erow[F4PL], ecol[F4PL];
+    long eoff[F4PL];
+    float4 bias4[F4PL], gam4[F4PL], bet4[F4PL], temb4[F4PL], res4[F4PL];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < F4PL; ++k) {
+        const int j = lp + k * lpp;                    // float4 index inside the pair
+        const int r = j >> cq_sh;
+        erow[k] = ps * Lout + r;                       // tile row (position)
+        ecol[k] = pg * cpg + (j & (cq - 1)) * 4;       // tile column (channel)
+        const int s = erow[k] >> p.lshift;
+        const int l = erow[k] & (Lout - 1);
+        const int em = m0 + ecol[k];
+        if (!p.interleave) {
+            eoff[k] = ((long)(s0 + s) * Lout + l) * M + em;
+        } else {
+            const int half = M >> 1;
+            const int phase = em >= half;
+            eoff[k] = ((long)(s0 + s) * (2 * Lout) + 2 * l + phase) * half + (em - phase * half);
+        }
+        if (s >= nvalid) eoff[k] = -1;
+    }
+    // Per-channel parameters and the residual tile.  With few registers at stake (F4PL <= 2)
+    // they are fetched before the K loop (their latency merges with the first weight loads);
+    // wide-tile variants fetch them after the LDS exchange instead.
+    constexpr bool EARLY_PARAMS = F4PL <= 2;
+    // (no lambda here: capturing the ownership arrays by reference would park them in scratch)
+#define DAD_FETCH_PARAMS()                                                                       \
+    _Pragma("unroll") for (int k = 0; k < F4PL; ++k) {                                           \
+        const int em = m0 + ecol[k];                                                             \
+        bias4[k] = *reinterpret_cast<const float4*>(p.bias + em);                                \
+        gam4[k] = has_gn ? *reinterpret_cast<const float4*>(p.gamma + em) : zero4;               \
+        bet4[k] = has_gn ? *reinterpret_cast<const float4*>(p.beta + em) : zero4;                \
+        temb4[k] = p.temb != nullptr ? *reinterpret_cast<const float4*>(p.temb + em) : zero4;    \
+        res4[k] = (p.res != nullptr && !p.interleave && eoff[k] >= 0)                            \
+                      ? *reinterpret_cast<const float4*>(p.res + eoff[k]) : zero4;               \
+    }
+    if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }
+
     load_stage(c_begin);                   // first global loads fly while LDS is being zeroed
     // zero both X stages once: halo rows (and rows of samples that do not exist) stay zero,
     // staging only ever writes real positions.  (XF is a multiple of 4 floats.)
@@ -290,6 +408,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     if (c_begin + 1 < nchunks) load_stage(c_begin + 1);
     __syncthreads();
     float4 ca = frag_a(0, 0), cb = frag_b(0, 0);
+    DAD_STAMP(1);
+    DAD_CLOCK(6);
 
     for (int ch = c_begin; ch < nchunks; ++ch) {
         const int cur = (ch - c_begin) & 1;
@@ -319,6 +439,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         }
     }
     __syncthreads();                       // all MFMAs retired before the stage memory is reused
+    DAD_STAMP(2);
+    DAD_CLOCK(7);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 
@@ -330,61 +452,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     //    xor-shuffles inside the wave, an LDS hop when a pair spans several waves), then
     //    normalises, applies Mish, adds time embedding / residual and stores — without touching
     //    LDS again.
-    constexpr int ES = BM + 4;
-    constexpr int ECOPY = BN * ES;
-    constexpr int F4PL = (BN * BM / 4) / NT;           // float4 per thread
-    static_assert(F4PL >= 1 && (BN * BM / 4) % NT == 0, "epilogue mapping");
     float* E = smem;                                   // [SK][BN][ES]
     float* red = smem + SK * ECOPY;                    // [2][waves] cross-wave partials
 #ifdef DAD_ABLATE_NOEPI
     if (p.B > 0) { if (acc[0] == 123.456f) p.dst[0] = acc[1]; return; }
 #endif
-#ifdef DAD_ABLATE_GN
-    const bool has_gn = false;
-#else
-    const bool has_gn = p.gamma != nullptr;
-#endif
-    // ownership: GroupNorm -> lanes of a pair are contiguous; otherwise plain row-major
-    const int cpg = has_gn ? p.cpg : BM;
-    const int cq = cpg >> 2;                           // float4 per row of a pair
-    const int cnt4 = has_gn ? (Lout * cq) : (BN * cq); // float4 per pair
-    const int lpp = cnt4 / F4PL;                       // lanes per pair (power of two >= 1)
-    const int gpt = BM / cpg;
-    const int pr = tid / lpp;
-    const int lp = tid - pr * lpp;
-    const int ps = has_gn ? pr / gpt : 0;              // sample of the pair
-    const int pg = has_gn ? pr - ps * gpt : 0;         // group of the pair
-    int erow[F4PL], ecol[F4PL];
-    long eoff[F4PL];
-    float4 bias4[F4PL], gam4[F4PL], bet4[F4PL], add4[F4PL];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < F4PL; ++k) {
-        const int j = lp + k * lpp;                    // float4 index inside the pair
-        const int r = j / cq;
-        erow[k] = ps * Lout + r;                       // tile row (position)
-        ecol[k] = pg * cpg + (j - r * cq) * 4;         // tile column (channel)
-        const int s = erow[k] >> p.lshift;
-        const int l = erow[k] & (Lout - 1);
-        const int em = m0 + ecol[k];
-        bias4[k] = *reinterpret_cast<const float4*>(p.bias + em);
-        gam4[k] = has_gn ? *reinterpret_cast<const float4*>(p.gamma + em) : zero4;
-        bet4[k] = has_gn ? *reinterpret_cast<const float4*>(p.beta + em) : zero4;
-        add4[k] = p.temb != nullptr ? *reinterpret_cast<const float4*>(p.temb + em) : zero4;
-        if (!p.interleave) {
-            eoff[k] = ((long)(s0 + s) * Lout + l) * M + em;
-            if (p.res != nullptr && s < nvalid) {
-                const float4 rv = *reinterpret_cast<const float4*>(p.res + eoff[k]);
-                add4[k].x += rv.x; add4[k].y += rv.y; add4[k].z += rv.z; add4[k].w += rv.w;
-            }
-        } else {
-            const int half = M >> 1;
-            const int phase = em >= half;
-            eoff[k] = ((long)(s0 + s) * (2 * Lout) + 2 * l + phase) * half + (em - phase * half);
-        }
-        if (s >= nvalid) eoff[k] = -1;
-    }
-
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -392,6 +464,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         E[ks * ECOPY + row * ES + col] = acc[r];
     }
     __syncthreads();
+    DAD_STAMP(3);
+    if (!EARLY_PARAMS) { DAD_FETCH_PARAMS() }
+#undef DAD_FETCH_PARAMS
 
     float y[F4PL][4];
 #pragma unroll
@@ -458,7 +533,13 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int width = lpp < 64 ? lpp : 64;
         const int wpp = lpp >> 6;                      // waves per pair when a pair spans waves
         auto pair_sum = [&](float v, int slot) -> float {
-            for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            // all-reduce over the `width` contiguous lanes of the pair with cross-lane VALU ops
+            // (DPP quad / mirror permutes inside a row, v_readlane across rows): no LDS round trips
+            if (width >= 2) v += dpp_f32<0xB1>(v);           // quad_perm [1,0,3,2]
+            if (width >= 4) v += dpp_f32<0x4E>(v);           // quad_perm [2,3,0,1]
+            if (width >= 8) v += dpp_f32<0x141>(v);          // row_half_mirror
+            if (width >= 16) v += dpp_f32<0x140>(v);         // row_mirror
+            if (width >= 32) v = rows_sum(v, width, lane);   // rows 0+1 | 2+3, then halves
             if (wpp > 1) {                             // block-uniform branch
                 if (lane == 0) red[slot * 16 + wave] = v;
                 __syncthreads();
@@ -486,13 +567,15 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             y[k][3] = mish_fast_f32((y[k][3] - mean) * rstd * gam4[k].w + bet4[k].w);
         }
     }
+    DAD_STAMP(4);
 #pragma unroll
     for (int k = 0; k < F4PL; ++k) {
         if (eoff[k] < 0) continue;
         *reinterpret_cast<float4*>(p.dst + eoff[k]) =
-            make_float4(y[k][0] + add4[k].x, y[k][1] + add4[k].y, y[k][2] + add4[k].z,
-                        y[k][3] + add4[k].w);
+            make_float4(y[k][0] + (temb4[k].x + res4[k].x), y[k][1] + (temb4[k].y + res4[k].y),
+                        y[k][2] + (temb4[k].z + res4[k].z), y[k][3] + (temb4[k].w + res4[k].w));
     }
+    DAD_STAMP(5);
 }
 
 }  // namespace dad

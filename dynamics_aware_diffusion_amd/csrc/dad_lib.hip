@@ -22,6 +22,9 @@ namespace {
 thread_local char g_err[1024] = "";
 int g_force_tile = -1;      // dad_debug_set_tile: tuning / test hook
 bool g_split_enabled = true;
+#ifdef DAD_STAMPS
+unsigned long long* g_stamps = nullptr;
+#endif
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -183,7 +186,7 @@ int build_plan(dad_model* m) {
         op.name = name; op.norm = norm; op.kind = kind;
         op.cin0 = cin0; op.cin1 = cin1;
         op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
-        const int padto = op.kc == 8 ? 8 : 32;          // KC=16 and KC=32 kernels share a packing
+        const int padto = op.kc == 8 ? 8 : (kind == CONV_1X1 ? 128 : 32);   // deepest K chunk of its kernels
         op.cin_pad = (cin0 + cin1 + padto - 1) / padto * padto;
         op.cout = cout; op.src0 = src0; op.src1 = src1; op.dst = dst; op.res = res;
         op.temb_off = toff; op.Lin = Lin;
@@ -381,16 +384,25 @@ template <> struct Tile<5> { static constexpr int BM = 32, BN = 64, SK = 2, KC =
 template <> struct Tile<6> { static constexpr int BM = 32, BN = 64, SK = 1, KC = 16; };
 template <> struct Tile<7> { static constexpr int BM = 64, BN = 64, SK = 2, KC = 16; };
 
+// 1x1 convs have one (tap, group) unit per 8 channels: a deep K chunk keeps enough MFMAs between
+// barriers (128 channels; 64 for the 128-row tile, whose stage would not fit LDS twice).
+constexpr int eff_kc(int cfg_kc, int bm, int taps) {
+    return (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128) : cfg_kc;
+}
+
 template <int CFG, int TAPS, int STRIDE>
 int launch_conv_t(ConvParams& p, hipStream_t st) {
     using T = Tile<CFG>;
-    const bool ragged = (p.cin0 & 3) != 0;
+    constexpr int KC = eff_kc(T::KC, T::BM, TAPS);
+    const int cin = p.cin0 + p.cin1;
+    const bool ragged = (p.cin0 & 3) != 0 || (p.cin1 & 3) != 0 || p.cin0 % KC != 0 || cin % KC != 0;
     if (ragged && !(STRIDE == 1 && (TAPS == 5 || TAPS == 1)))
-        return fail(DAD_E_INVALID, "ragged channel count only supported for the first block");
+        return fail(DAD_E_INVALID, "channel count %d+%d needs the general staging path, which exists "
+                    "for stride-1 5-tap and 1x1 convs only", p.cin0, p.cin1);
     auto kern = (ragged && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
-                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, 1, true>
-                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE, false>;
-    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, T::KC, TAPS, p.Lin, p.Lout, T::SK) * sizeof(float);
+                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true>
+                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false>;
+    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, KC, TAPS, p.Lin, p.Lout, T::SK) * sizeof(float);
     const int spt = T::BN / p.Lout;
     p.ntiles_n = (p.B + spt - 1) / spt;
     const int nblocks = p.ntiles_n * (p.M / T::BM) * p.kslices;
@@ -404,13 +416,14 @@ int launch_conv_t(ConvParams& p, hipStream_t st) {
 template <int CFG, int TAPS, int STRIDE>
 hipError_t raise_lds_limit() {
     using T = Tile<CFG>;
+    constexpr int KC = eff_kc(T::KC, T::BM, TAPS);
     hipError_t e = hipFuncSetAttribute(
-        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, STRIDE, false>,
+        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false>,
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     if (STRIDE == 1 && (TAPS == 5 || TAPS == 1))
         e = hipFuncSetAttribute(
-            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, T::KC, TAPS, 1, true>,
+            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true>,
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
@@ -491,7 +504,8 @@ SplitPlan plan_split(const ConvOp& op, int cfg, int batch) {
     const TileCfg& t = kTiles[cfg];
     const int spt = t.BN / op.Lout;
     const long tiles = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
-    const int nchunks = op.cin_pad / t.KC;
+    const int kc = eff_kc(t.KC, t.BM, op.taps);
+    const int nchunks = (op.cin0 + op.cin1 + kc - 1) / kc;      // chunks holding real channels
     SplitPlan sp{1, nchunks, 0};
     if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
     int want = (int)((256 + tiles - 1) / tiles);
@@ -531,16 +545,21 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.cin0 = op.cin0; p.cin1 = op.cin1; p.cin_pad = op.cin_pad;
     p.M = op.M; p.cpg = op.norm.empty() ? 0 : op.cout / 8;
     p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout; p.lshift = ilog2(op.Lout);
+    p.lshift_in = ilog2(op.Lin);
     p.interleave = op.kind == CONV_UP;
     const int cfg = choose_tile(op, batch);
     if (cfg < 0)
         return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
                     op.name.c_str(), op.M, op.cout / 8, op.Lout);
-    const SplitPlan sp = g_split_enabled ? plan_split(op, cfg, batch) : SplitPlan{1, op.cin_pad / kTiles[cfg].KC, 0};
+    const SplitPlan sp = g_split_enabled ? plan_split(op, cfg, batch)
+                                         : SplitPlan{1, op.cin_pad, 0};   // one slice: every chunk
     p.kslices = sp.kslices;
     p.chunks_per_slice = sp.chunks_per_slice;
     p.slab = ws + m->plan.floats_per_sample * (long)batch;     // scratch behind the activations
     p.counters = m->d_counters;
+#ifdef DAD_STAMPS
+    p.stamps = g_stamps ? g_stamps + (size_t)(&op - &m->plan.convs[0]) * 4096 * 8 : nullptr;
+#endif
     int rc;
     switch (cfg) {
         case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, st); break;
@@ -921,6 +940,10 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, u
     HIP_TRY(hipGetLastError());
     return DAD_OK;
 }
+
+#ifdef DAD_STAMPS
+int dad_debug_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return DAD_OK; }
+#endif
 
 int dad_debug_set_tile(int32_t cfg) {
     // cfg >= 100: same, with grid-level split-K disabled (cfg - 100 is the tile, 99 = heuristic)
