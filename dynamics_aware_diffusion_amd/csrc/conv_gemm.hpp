@@ -29,6 +29,16 @@
 
 namespace dad {
 
+// -DDAD_W_DMA=1 stages the weight slabs global -> LDS directly (LDS-DMA, global_load_lds_dwordx4,
+// XOR-swizzled lane-linear image) instead of through registers.  Measured on MI355X at the bench
+// workload: 99.0 ms per loop against 88.2 ms for register staging (five 1-KiB DMA pieces per wave
+// and chunk cost more issue time beside the MFMAs than five global_load_dwordx4 + ds_write_b128),
+// so the default is register staging; the variant is kept for A/B on other shapes.
+#ifndef DAD_W_DMA
+#define DAD_W_DMA 0
+#endif
+constexpr bool kWDma = DAD_W_DMA != 0;
+
 #ifdef DAD_STAMPS
 #define DAD_STAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -114,6 +124,12 @@ __device__ __forceinline__ float rows_sum(float v, int width, int lane) {
     return lane < 32 ? lo : hi;
 }
 
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform base + lane*16).
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 // Rows of the X stage: every sample of the tile with its zero halo.
 __host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
     return (BN / Lout) * (Lin + 2 * (taps / 2));
@@ -122,7 +138,8 @@ __host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
 __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int taps, int Lin,
                                                   int Lout, int SK) {
     const size_t kp = KC + 4;
-    const size_t stage = ((size_t)conv_xrows(BN, Lin, Lout, taps) + (size_t)taps * BM) * kp;
+    const size_t stage = (size_t)conv_xrows(BN, Lin, Lout, taps) * kp +
+                         (size_t)taps * BM * (kWDma ? (size_t)KC : kp);
     const size_t epi = (size_t)SK * BN * (BM + 4) + 64;
     const size_t k = 2 * stage;
     return k > epi ? k : epi;
@@ -184,14 +201,23 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int nvalid = min(SPT, p.B - s0);
 
     const int XF = XROWS * KP;
-    const int STAGE = XF + TAPS * BM * KP;       // floats per stage: [X rows][W rows]
+    constexpr int WP = kWDma ? KC : KP;          // W row stride: DMA images are lane-linear (unpadded)
+    const int STAGE = XF + TAPS * BM * WP;       // floats per stage: [X rows][W rows]
 
 
     // A operand (activations): lane's GEMM row n -> LDS row of tap 0
     const int n_loc = tn * 32 + l32;
     const int arow = ((n_loc >> p.lshift) * SEG + (n_loc & (Lout - 1)) * STRIDE) * KP + 4 * h;
     // B operand (weights): lane's output channel
-    const int brow = XF + (tm * 32 + l32) * KP + 4 * h;
+    // LDS-DMA writes 64 lanes x 16 B linearly, so W rows cannot be padded; bank conflicts of the
+    // ds_read_b128 are removed by XOR-swizzling the 16-B slot inside a row with the row index
+    // (applied on the DMA's per-lane SOURCE address and on the read; guide rule 21).
+    constexpr int SPR = KC / 4;                              // 16-B slots per W row
+    constexpr int SWZ_SHIFT = SPR >= 16 ? 0 : (SPR == 8 ? 1 : SPR == 4 ? 2 : 3);
+    constexpr int SWZ_MASK = SPR >= 16 ? 15 : SPR - 1;
+    const int brow = kWDma ? XF + (tm * 32 + l32) * WP
+                           : XF + (tm * 32 + l32) * KP + 4 * h;
+    const int bswz = ((tm * 32 + l32) >> SWZ_SHIFT) & SWZ_MASK;   // (tap*BM adds 0 mod the mask)
 
     // two independent accumulation chains per wave (even / odd k-steps), summed in the epilogue
     f32x16 acc, acc2;
@@ -244,18 +270,47 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         x_loff[i] = e < xrows_real * KQ ? (s * SEG + PAD + l) * KP + q * 4 : -1;
     }
     const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
+    // LDS-DMA descriptors of this wave: instruction q moves the 1 KiB [q*256, q*256+256) floats of
+    // the W image; lane -> (row, physical slot) -> swizzled logical slot -> packed global address.
+    constexpr int NWAVES = WT * SK;
+    constexpr int W_INSTR = TAPS * BM * KC / 256;
+    constexpr int D_PER_W = (W_INSTR + NWAVES - 1) / NWAVES;
+    int d_goff[D_PER_W];
+    if (kWDma) {
+#pragma unroll
+        for (int i = 0; i < D_PER_W; ++i) {
+            const int q = wave + i * NWAVES;
+            const int fl = q * 256 + lane * 4;                  // float index inside the W image
+            const int row = fl / KC;                            // tap*BM + m
+            const int ps = (fl - row * KC) >> 2;                // physical 16-B slot in the row
+            const int sl = ps ^ ((row >> SWZ_SHIFT) & SWZ_MASK);// logical slot stored there
+            const int tap = row / BM;
+            const int mm = row - tap * BM;
+            const int sub = sl / GQ;
+            d_goff[i] = ((sub * TAPS + tap) * M + m0 + mm) * KG + (sl - sub * GQ) * 4;
+        }
+    }
     // RAGGED = false promises (host-checked) that every K chunk lies inside one concat source and
     // below cin, with 16-byte aligned channel quads: the X loads use one base pointer per chunk.
     // RAGGED = true is the general path: first layer (cin = transition_dim), narrow nets.
 
     auto load_stage = [&](int chunk) {
         const float* wsrc = p.w + chunk * w_chunk_stride;
+        if constexpr (kWDma) {
+            float* wimg = smem + ((chunk - c_begin) & 1) * STAGE + XF;
 #pragma unroll
-        for (int i = 0; i < W_PER_T; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (W_F4 % NT == 0 || tid + i * NT < W_F4)
-                v = *reinterpret_cast<const float4*>(wsrc + w_goff[i]);
-            wreg[i] = v;
+            for (int i = 0; i < D_PER_W; ++i) {
+                const int q = wave + i * NWAVES;
+                if (W_INSTR % NWAVES == 0 || q < W_INSTR) glds16(wsrc + d_goff[i], wimg + q * 256);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < W_PER_T; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (W_F4 % NT == 0 || tid + i * NT < W_F4)
+                    v = *reinterpret_cast<const float4*>(wsrc + w_goff[i]);
+                wreg[i] = v;
+            }
         }
         const int c0 = chunk * KC;
         if constexpr (!RAGGED) {
@@ -298,10 +353,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     };
     auto store_stage = [&](int stage) {
         const int base = stage * STAGE;
+        if constexpr (!kWDma) {
 #pragma unroll
-        for (int i = 0; i < W_PER_T; ++i)
-            if (W_F4 % NT == 0 || tid + i * NT < W_F4)
-                *reinterpret_cast<float4*>(&smem[base + w_loff[i]]) = wreg[i];
+            for (int i = 0; i < W_PER_T; ++i)
+                if (W_F4 % NT == 0 || tid + i * NT < W_F4)
+                    *reinterpret_cast<float4*>(&smem[base + w_loff[i]]) = wreg[i];
+        }
 #pragma unroll
         for (int i = 0; i < X_PER_T; ++i)
             if (x_loff[i] >= 0) *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = xreg[i];
@@ -325,9 +382,15 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int tap = u / GW, gw = u - tap * GW;
         return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * 8]);
     };
+    int bsl[GW];                                        // swizzled slot offsets (floats), per group
+#pragma unroll
+    for (int gw = 0; gw < GW; ++gw) bsl[gw] = (((ks * GW + gw) * 2 + h) ^ bswz) * 4;
     auto frag_b = [&](int stage, int u) -> float4 {
         const int tap = u / GW, gw = u - tap * GW;
-        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * 8]);
+        if constexpr (kWDma)
+            return *reinterpret_cast<const float4*>(&smem[stage * STAGE + brow + tap * BM * WP + bsl[gw]]);
+        else
+            return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * 8]);
     };
 
     // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
@@ -406,6 +469,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     __syncthreads();                       // zero fill done before real rows land
     store_stage(0);
     if (c_begin + 1 < nchunks) load_stage(c_begin + 1);
+    if constexpr (kWDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first W images landed
     __syncthreads();
     float4 ca = frag_a(0, 0), cb = frag_b(0, 0);
     DAD_STAMP(1);
@@ -416,17 +480,29 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
             float4 na = ca, nb = cb;
+            // (DAD_ABLATE_* exist only in timing-only diagnostic builds: wrong results by design)
             if (u + 1 < UW) {
+#ifndef DAD_ABLATE_LDSREAD
                 na = frag_a(cur, u + 1);
                 nb = frag_b(cur, u + 1);
+#endif
             } else {
+#ifndef DAD_ABLATE_STAGE
                 if (ch + 1 < nchunks) store_stage(cur ^ 1);
+#endif
+                if constexpr (kWDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // DMA landed
+#ifndef DAD_ABLATE_BARRIER
                 __syncthreads();
+#endif
+#ifndef DAD_ABLATE_STAGE
                 if (ch + 2 < nchunks) load_stage(ch + 2);
+#endif
+#ifndef DAD_ABLATE_LDSREAD
                 if (ch + 1 < nchunks) {
                     na = frag_a(cur ^ 1, 0);
                     nb = frag_b(cur ^ 1, 0);
                 }
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
