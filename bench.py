@@ -133,6 +133,7 @@ def main() -> None:
     od, ad, dim, mults, T = synth.ARCHS[arch]
     td = od + ad
     policy, diff, cond, state = build_policy(arch, device)
+    diff.use_graph = batch <= 32          # small batches are launch-bound: replay one hipGraph
     gathered = torch.empty(world * batch, 32, td, device=device) if world > 1 else None
 
     def one_step(k: int):
@@ -165,6 +166,7 @@ def main() -> None:
     roof = None
     if rank == 0:
         eng = diff._engine(device)
+        diff.use_graph = False                # events are recorded on eager launches
         eng.profile_enable(True)
         one_step(10_000)
         torch.cuda.synchronize()
@@ -205,7 +207,7 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "arch": arch, "batch_per_gpu": batch,
                        "global_batch": world * batch, "horizon": 32, "denoise_steps": T,
-                       "rng": "in-kernel philox", "sharding": f"batch x{world}, gather at end"},
+                       "rng": "in-kernel philox", "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end"},
             "roofline": roof, "cpu_baseline": base,
         }
         print(json.dumps(out))

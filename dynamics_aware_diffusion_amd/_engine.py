@@ -161,6 +161,7 @@ class HipEngine:
         _check(self.lib, self.lib.dad_model_create(C.byref(cfg), C.byref(handle)))
         self._h = handle
         self._ws: Dict[int, torch.Tensor] = {}
+        self._pinned: Dict[tuple, torch.Tensor] = {}
         self.ready = False
 
     def __del__(self):
@@ -209,6 +210,16 @@ class HipEngine:
             ws = torch.empty(max(n.value, 4) // 4 + 4, dtype=torch.float32, device=self.device)
             self._ws[batch] = ws
         return ws
+
+    def persistent(self, tag: str, shape) -> torch.Tensor:
+        """A device tensor with a stable address per (tag, shape): hipGraph replays freeze the
+        pointers they were captured with."""
+        key = (tag, tuple(shape))
+        t = self._pinned.get(key)
+        if t is None:
+            t = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+            self._pinned[key] = t
+        return t
 
     def _traj(self, x: torch.Tensor, name: str = "x") -> int:
         _require_device(x, name)

@@ -102,7 +102,8 @@ const TileCfg kTiles[] = {
 
 struct GraphKey {
     const void* x; const void* noise; const void* cond; const void* ws; const void* P;
-    int n_steps, batch, cond_per_row;
+    int n_steps, batch, cond_per_row, pad_ = 0;
+    uint64_t row_offset;
     bool operator<(const GraphKey& o) const {
         return std::memcmp(this, &o, sizeof(GraphKey)) < 0;
     }
@@ -615,7 +616,8 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
 }
 
 int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const dad_step_args* a,
-              int x_out_disabled, float* eps_only, float* ws, hipStream_t st) {
+              int x_out_disabled, float* eps_only, float* ws, hipStream_t st,
+              bool seed_from_device = false) {
     const dad_cfg& c = m->cfg;
     dad::FinalParams p{};
     p.act = ws + m->plan.bufs[m->plan.final_act].offset * (long)batch;
@@ -640,6 +642,7 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         p.seed = a->seed;
         p.elem_offset = a->row_offset * (uint64_t)c.horizon * (uint64_t)c.transition_dim;
         p.draw = a->draw;
+        p.seed_dev = seed_from_device ? (const unsigned long long*)m->d_rng : nullptr;
     }
     const size_t lds = dad::final_lds_floats(c.transition_dim, c.dim) * sizeof(float);
     if (lds > 160 * 1024)
@@ -881,6 +884,7 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     hipStream_t st = (hipStream_t)stream;
     const long step_elems = (long)batch * m->cfg.horizon * m->cfg.transition_dim;
 
+    const bool seed_dev = use_graph && !m->profile && noise_stack == nullptr;
     auto enqueue_all = [&](hipStream_t st) -> int {
         for (int j = 0; j < n_steps; ++j) {
             const int t = n_steps - 1 - j;
@@ -890,7 +894,8 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
             a.cond0 = cond0; a.cond_per_row = cond_per_row;
             int r = run_unet(m, x, t, batch, (float*)workspace, st);
             if (r != DAD_OK) return r;
-            if ((r = run_final(m, x, nullptr, t, batch, &a, 0, nullptr, (float*)workspace, st)) != DAD_OK)
+            if ((r = run_final(m, x, nullptr, t, batch, &a, 0, nullptr, (float*)workspace, st,
+                               seed_dev)) != DAD_OK)
                 return r;
             if (proj && (r = run_project(proj, proj_alphas_host[t], x, batch, m->cfg.horizon, st)) != DAD_OK)
                 return r;
@@ -900,18 +905,25 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
 
     if (!use_graph || m->profile) return enqueue_all(st);
 
-    // Graph replay: the whole T-step loop is one hipGraph keyed by every frozen pointer.
-    // Philox seeds are frozen too, so graphs are only used with an injected noise stack or
-    // when the caller accepts a per-(seed) capture; the seed is part of nothing here —
-    // callers wanting fresh noise per call pass noise_stack they refill (dad_fill_normal).
-    if (!noise_stack)
-        return fail(DAD_E_INVALID, "use_graph requires a noise stack (refill it with dad_fill_normal)");
+    // Graph replay: the whole T-step loop is one hipGraph keyed by every frozen pointer and
+    // scalar.  With in-kernel noise the Philox key is read from device memory, written by a
+    // tiny kernel ahead of the replay, so a new seed does not need a new capture.
+    if (seed_dev) {
+        hipLaunchKernelGGL(dad::set_u64_kernel, dim3(1), dim3(1), 0, st,
+                           (unsigned long long*)m->d_rng, (unsigned long long)seed);
+        HIP_TRY(hipGetLastError());
+    }
     GraphKey key{};
     key.x = x; key.noise = noise_stack; key.cond = cond0; key.ws = workspace;
     key.P = proj ? proj->P : nullptr;
     key.n_steps = n_steps; key.batch = batch; key.cond_per_row = cond_per_row;
+    key.row_offset = row_offset;
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
+        if (m->graphs.size() >= 16) {                 // bounded cache: drop everything, re-capture
+            for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+            m->graphs.clear();
+        }
         // capture on a private stream: the caller's stream may be the null stream, which
         // cannot be captured; nothing executes during capture.
         if (!m->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));

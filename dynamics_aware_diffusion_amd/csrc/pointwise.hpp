@@ -48,6 +48,8 @@ __device__ __forceinline__ float philox_normal(uint64_t e, uint64_t draw, uint64
     return (e & 1) ? rad * sinf(ang) : rad * cosf(ang);
 }
 
+__global__ void set_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst = v; }
+
 __global__ void fill_normal_kernel(float* x, long n_elems, uint64_t elem_offset, uint64_t draw,
                                    uint64_t seed) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,6 +75,8 @@ struct FinalParams {
     float sigma;             // [t != 0] * exp(0.5 * log_var_t)
     float guide_scale;       // guide_weight * exp(log_var_t)      (policies.py:97)
     uint64_t seed, elem_offset, draw;
+    const unsigned long long* seed_dev;   // when set, the Philox key is read from device memory
+                                          // (graph replays take a fresh seed without re-capture)
 };
 
 constexpr int FINAL_COLS = 64;   // trajectory positions per block
@@ -127,7 +131,8 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
         if (p.x_out_disabled) continue;
         const float z = (p.noise != nullptr)
                             ? p.noise[idx]
-                            : philox_normal(p.elem_offset + (uint64_t)idx, p.draw, p.seed);
+                            : philox_normal(p.elem_offset + (uint64_t)idx, p.draw,
+                                            p.seed_dev != nullptr ? (uint64_t)*p.seed_dev : p.seed);
         float xn = mean + p.sigma * z;
         if (l == 0 && p.cond0 != nullptr) xn = p.cond0[(p.cond_per_row ? (long)b * td : 0) + j];
         p.x[idx] = xn;

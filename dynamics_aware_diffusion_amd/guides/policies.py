@@ -108,16 +108,22 @@ class GuidedPolicy(nn.Module):
         diff._check_step(n_steps - 1)
         eng = diff._engine(device)
         philox = diff.sampler_rng == "philox"
+        graph = bool(diff.use_graph) and not self._guided()
         if philox:
-            x = torch.empty(shape, device=device, dtype=torch.float32)
+            x = eng.persistent("x", shape) if graph else \
+                torch.empty(shape, device=device, dtype=torch.float32)
             eng.fill_normal(x, diff.seed, row_offset=row_offset, draw=0)
         else:
             x = torch.randn(shape, device=device)
+            if graph:
+                x = eng.persistent("x", shape).copy_(x)
         if conditions is not None:
             conditions = {k: v.to(device, torch.float32) for k, v in conditions.items()}
             x = self.apply_conditions(x, conditions)
         cond0, rest = self._split_conditions(conditions)
         c0 = None if cond0 is None else cond0.contiguous()
+        if graph and c0 is not None:                       # frozen pointer: stage the condition
+            c0 = eng.persistent("cond0", tuple(c0.shape)).copy_(c0)
         projector = self._loop_projector()
 
         if not self._guided() and not rest:
@@ -126,14 +132,15 @@ class GuidedPolicy(nn.Module):
                 alphas = [self._get_projection_alpha(i) for i in range(int(diff.betas.shape[0]))]
             if philox:
                 eng.sample_loop(x, n_steps, seed=diff.seed, row_offset=row_offset, cond0=c0,
-                                projection=projector, proj_alphas=alphas)
+                                projection=projector, proj_alphas=alphas, use_graph=graph)
             else:
-                stack = torch.empty((n_steps,) + shape, device=device)
+                stack = eng.persistent("z", (n_steps,) + shape) if graph else \
+                    torch.empty((n_steps,) + shape, device=device)
                 for j in range(n_steps):
                     torch.randn(shape, out=stack[j])
                 eng.sample_loop(x, n_steps, noise_stack=stack, cond0=c0, projection=projector,
-                                proj_alphas=alphas, use_graph=diff.use_graph)
-            return x
+                                proj_alphas=alphas, use_graph=graph)
+            return x.clone() if graph else x
 
         # guided (or multi-step-conditioned) path: one engine step per iteration, the guide
         # gradient comes from PyTorch autograd on the user's value model.

@@ -80,6 +80,10 @@ class GaussianDiffusion(nn.Module):
       like the reference would on the same device;
     * ``"philox"`` uses the engine's in-kernel counter-based generator (no noise tensors,
       sharding-invariant) — the throughput path.
+
+    ``use_graph = True`` replays the whole T-step loop as one cached hipGraph (persistent
+    input buffers, result returned as a copy): removes the per-launch host cost that dominates
+    small batches such as the B=1 plans of ``get_action``.
     """
 
     def __init__(self, model: TemporalUnet, horizon: int, observation_dim: int, action_dim: int,
@@ -179,16 +183,21 @@ class GaussianDiffusion(nn.Module):
         n_steps = int(self.n_timesteps)
         self._check_step(n_steps - 1)
         if self.sampler_rng == "philox":
-            x = torch.empty(shape, device=device, dtype=torch.float32)
+            x = eng.persistent("x", shape) if self.use_graph else \
+                torch.empty(shape, device=device, dtype=torch.float32)
             eng.fill_normal(x, self.seed, row_offset=row_offset, draw=0)
-            eng.sample_loop(x, n_steps, seed=self.seed, row_offset=row_offset)
-            return x
+            eng.sample_loop(x, n_steps, seed=self.seed, row_offset=row_offset,
+                            use_graph=self.use_graph)
+            return x.clone() if self.use_graph else x
         x = torch.randn(shape, device=device)
-        stack = torch.empty((n_steps,) + tuple(shape), device=device)
+        if self.use_graph:
+            x = eng.persistent("x", shape).copy_(x)
+        stack = eng.persistent("z", (n_steps,) + tuple(shape)) if self.use_graph else \
+            torch.empty((n_steps,) + tuple(shape), device=device)
         for j in range(n_steps):
             torch.randn(tuple(shape), out=stack[j])
         eng.sample_loop(x, n_steps, noise_stack=stack, use_graph=self.use_graph)
-        return x
+        return x.clone() if self.use_graph else x
 
     # ------------------------------------------------------------------ training objective
     def loss(self, x_start, weights=None):

@@ -260,3 +260,35 @@ def test_weights_refresh_after_load_state_dict(dev):
             want = orc.unet_forward(w, x, torch.full((3,), 4, dtype=torch.long))
         got = diff.model(x.to(dev), 4)
         assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, seed
+
+
+def test_graph_replay_with_inkernel_noise(dev):
+    """hipGraph replay of the whole loop with the Philox key read from device memory: identical
+    to eager launches, and a new seed needs no new capture."""
+    from dynamics_aware_diffusion_amd import GuidedPolicy
+    diff = build("tiny", 20, "cosine", dev)
+    diff.sampler_rng = "philox"
+    pol = GuidedPolicy(diff, cases.NormalizerStub(4, 2), action_horizon=3)
+    cond = {0: torch.from_numpy(cases.loop_condition("graphphilox", "tiny")).to(dev)}
+    try:
+        outs = {}
+        for graph in (False, True):
+            diff.use_graph = graph
+            for seed in (11, 12, 11):
+                diff.seed = seed
+                x = pol.sample_loop(batch_size=3, conditions=cond)
+                u = diff.p_sample_loop((2, 32, 6))
+                torch.cuda.synchronize()
+                outs.setdefault((graph, seed), []).append((x.cpu().numpy().copy(), u.cpu().numpy().copy()))
+        for seed in (11, 12):
+            e, g = outs[(False, seed)][0], outs[(True, seed)][0]
+            assert np.array_equal(e[0], g[0]) and np.array_equal(e[1], g[1])
+        assert np.array_equal(outs[(True, 11)][0][0], outs[(True, 11)][1][0])      # replayed, same seed
+        assert not np.array_equal(outs[(True, 11)][0][0], outs[(True, 12)][0][0])  # new seed, same graph
+        # planner glue on top of a replayed B=1 plan
+        diff.use_graph = True
+        a = pol.get_action(np.zeros(4, np.float32))
+        assert a.shape == (2,) and np.isfinite(a).all() and len(pol.action_buffer) == 3
+    finally:
+        diff.use_graph = False
+        diff.sampler_rng = "torch"
