@@ -39,15 +39,23 @@ namespace dad {
 #endif
 constexpr bool kWDma = DAD_W_DMA != 0;
 
+#define DAD_LBID (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
 #ifdef DAD_STAMPS
-#define DAD_STAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DAD_STAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && DAD_LBID < 4096) p.stamps[DAD_LBID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define DAD_STAMP(i) do {} while (0)
 #endif
 #ifdef DAD_STAMPS
-#define DAD_CLOCK(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DAD_CLOCK(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && DAD_LBID < 4096) p.stamps[DAD_LBID * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DAD_CLOCK(i) do {} while (0)
+#endif
+#ifdef DAD_STAMPS_PROLOGUE   /* variant: the six stamps resolve the prologue instead */
+#define DAD_PSTAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && DAD_LBID < 4096) p.stamps[DAD_LBID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#undef DAD_STAMP
+#define DAD_STAMP(i) do { if ((i) == 0) DAD_PSTAMP(0); } while (0)
+#else
+#define DAD_PSTAMP(i) do {} while (0)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -176,20 +184,14 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int l32 = lane & 31;
     const int h = lane >> 5;
 
-    // XCD-aware tile order: hardware deals consecutive block ids round-robin over the 8 XCDs;
-    // give every XCD a contiguous run of tiles in M-major order so the blocks sharing one
-    // weight slab share an L2 (speed only; any placement is correct).
-    int tile;
-    {
-        const int nblk = gridDim.x;
-        const int bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int kb = tile % p.kslices;             // this block's K slice of its output tile
-    tile /= p.kslices;                           // slices of one tile are adjacent: same XCD
-    const int mt = tile / p.ntiles_n;
-    const int nt = tile - mt * p.ntiles_n;
+    // Grid = (K slices, M tiles, N tiles): no index arithmetic on the critical path to the first
+    // global load.  Hardware deals linear block ids (x fastest) round-robin over the 8 XCDs, so
+    // with this order the blocks that share a weight slab (same M tile) mostly share an XCD's
+    // L2, and the K slices of one tile are neighbours (speed only; any placement is correct).
+    const int kb = blockIdx.x;                   // this block's K slice of its output tile
+    const int mt = blockIdx.y;
+    const int nt = blockIdx.z;
+    const int tile = mt * p.ntiles_n + nt;       // id for the split-K slab / ticket
 
     const int Lin = p.Lin, Lout = p.Lout;
     const int SPT = BN >> p.lshift;              // whole samples per tile
@@ -457,9 +459,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         res4[k] = (p.res != nullptr && !p.interleave && eoff[k] >= 0)                            \
                       ? *reinterpret_cast<const float4*>(p.res + eoff[k]) : zero4;               \
     }
-    if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }
-
     load_stage(c_begin);                   // first global loads fly while LDS is being zeroed
+    if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }   // younger than the stage loads: not waited with them
+    DAD_PSTAMP(1);
     // zero both X stages once: halo rows (and rows of samples that do not exist) stay zero,
     // staging only ever writes real positions.  (XF is a multiple of 4 floats.)
     for (int i = tid * 4; i < XF; i += NT * 4) {
@@ -467,10 +469,14 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         *reinterpret_cast<float4*>(&smem[STAGE + i]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();                       // zero fill done before real rows land
+    DAD_PSTAMP(2);
     store_stage(0);
+    DAD_PSTAMP(3);
     if (c_begin + 1 < nchunks) load_stage(c_begin + 1);
+    DAD_PSTAMP(4);
     if constexpr (kWDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first W images landed
     __syncthreads();
+    DAD_PSTAMP(5);
     float4 ca = frag_a(0, 0), cb = frag_b(0, 0);
     DAD_STAMP(1);
     DAD_CLOCK(6);
@@ -567,8 +573,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         float* mine = p.slab + ((long)tile * KS + kb) * (BN * BM);
 #pragma unroll
         for (int k = 0; k < F4PL; ++k)
-            *reinterpret_cast<float4*>(mine + erow[k] * BM + ecol[k]) =
-                make_float4(y[k][0], y[k][1], y[k][2], y[k][3]);
+            if (eoff[k] >= 0)                         // rows of samples that exist (small batches)
+                *reinterpret_cast<float4*>(mine + erow[k] * BM + ecol[k]) =
+                    make_float4(y[k][0], y[k][1], y[k][2], y[k][3]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem + SK * ECOPY + 32);
@@ -590,6 +597,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const float* base = p.slab + (long)tile * KS * (BN * BM);
 #pragma unroll
         for (int k = 0; k < F4PL; ++k) {
+            if (eoff[k] < 0) continue;                // padding rows keep their (unused) partials
             const float* q = base + erow[k] * BM + ecol[k];
             float4 v = *reinterpret_cast<const float4*>(q);
             for (int c = 1; c < KS; ++c) {

@@ -406,8 +406,9 @@ int launch_conv_t(ConvParams& p, hipStream_t st) {
     const size_t lds = dad::conv_lds_floats(T::BM, T::BN, KC, TAPS, p.Lin, p.Lout, T::SK) * sizeof(float);
     const int spt = T::BN / p.Lout;
     p.ntiles_n = (p.B + spt - 1) / spt;
-    const int nblocks = p.ntiles_n * (p.M / T::BM) * p.kslices;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * (T::BM / 32) * (T::BN / 32) * T::SK), lds, st, p);
+    if (p.ntiles_n > 65535) return fail(DAD_E_INVALID, "batch too large for one launch (%d N tiles)", p.ntiles_n);
+    hipLaunchKernelGGL(kern, dim3(p.kslices, p.M / T::BM, p.ntiles_n),
+                       dim3(64 * (T::BM / 32) * (T::BN / 32) * T::SK), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;
 }
