@@ -121,13 +121,21 @@ def main() -> None:
                          f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the sampler has no CPU path")
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    # one rank per GPU; DAD_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box) folds ranks onto device 0
+    ngpu = torch.cuda.device_count()
+    share = os.environ.get("DAD_BENCH_SHARE_GPU") == "1"
+    device = torch.device("cuda", (local_rank % ngpu if share else local_rank) if world > 1 else 0)
     torch.cuda.set_device(device)
     dist = None
+    host_collectives = os.environ.get("DAD_BENCH_BACKEND", "nccl") != "nccl"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("DAD_BENCH_BACKEND", "nccl")        # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     arch, batch, desc = WORKLOADS[args.workload]
     od, ad, dim, mults, T = synth.ARCHS[arch]
@@ -140,7 +148,11 @@ def main() -> None:
         diff.seed = 1000 + k                                  # fresh noise every loop
         plans = policy.sample_loop(batch_size=batch, conditions=cond, row_offset=rank * batch)
         if dist is not None:                                   # collect finished plans (RCCL)
-            dist.all_gather_into_tensor(gathered, plans)
+            if host_collectives:                               # gloo rehearsal: stage through host
+                parts = [torch.empty(plans.shape) for _ in range(world)]
+                dist.all_gather(parts, plans.cpu())
+            else:
+                dist.all_gather_into_tensor(gathered, plans)
         return plans
 
     def fence():
@@ -157,7 +169,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if host_collectives else device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(plans).all()
@@ -168,7 +180,8 @@ def main() -> None:
         eng = diff._engine(device)
         diff.use_graph = False                # events are recorded on eager launches
         eng.profile_enable(True)
-        one_step(10_000)
+        diff.seed = 10_000                    # rank-0-only pass: NO collective in here
+        policy.sample_loop(batch_size=batch, conditions=cond, row_offset=rank * batch)
         torch.cuda.synchronize()
         conv_ms, launches, conv_flops = eng.profile_read()
         eng.profile_enable(False)
