@@ -111,6 +111,10 @@ def main() -> None:
     ap.add_argument("--workload", default="pointmaze_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent sampling loops kept in flight on separate HIP streams "
+                         "(diagnostic: shows how much of a step is dependency bubbles; the "
+                         "headline number uses 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,12 +164,27 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        one_step(k)
+    extra = []
+    if args.inflight > 1:                     # one policy/engine + stream per loop in flight
+        extra = [(build_policy(arch, device), torch.cuda.Stream(device)) for _ in range(args.inflight - 1)]
+
+    def run_steps(first: int, count: int):
+        out = None
+        for k in range(count):
+            slot = k % args.inflight
+            if slot == 0:
+                out = one_step(first + k)
+            else:
+                (pol_k, diff_k, cond_k, _), st = extra[slot - 1]
+                with torch.cuda.stream(st):
+                    diff_k.seed = 1000 + first + k
+                    pol_k.sample_loop(batch_size=batch, conditions=cond_k, row_offset=rank * batch)
+        return out
+
+    run_steps(0, max(args.warmup, args.inflight if args.inflight > 1 else 0))
     fence()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        plans = one_step(args.warmup + k)
+    plans = run_steps(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -220,7 +239,7 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "arch": arch, "batch_per_gpu": batch,
                        "global_batch": world * batch, "horizon": 32, "denoise_steps": T,
-                       "rng": "in-kernel philox", "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end"},
+                       "rng": "in-kernel philox", "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end", "loops_in_flight": args.inflight},
             "roofline": roof, "cpu_baseline": base,
         }
         print(json.dumps(out))
