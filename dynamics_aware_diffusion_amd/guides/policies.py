@@ -205,6 +205,41 @@ class GuidedPolicy(nn.Module):
         return self.action_buffer.pop(0)
 
 
+    # ------------------------------------------------------------------ batched planner glue
+    def get_actions(self, observations) -> np.ndarray:
+        """``get_action`` for N environments at once (not in the
+        reference): observations ``(N, observation_dim)`` -> actions ``(N, action_dim)``.
+
+        One B=N sampling loop with a per-row inpainting condition replaces N separate B=1 loops;
+        normalisation, the condition build and the action un-normalisation stay on the device, and
+        only the ``(N, k, action_dim)`` block of buffered actions crosses PCIe.  Every environment
+        follows the single-environment semantics: actions of horizon steps
+        0..min(action_horizon, H-1) are queued and served before the next replan
+        (policies.py:181-223).  All N queues are refilled together.
+        """
+        obs = np.asarray(observations, dtype=np.float32)
+        if obs.ndim != 2 or obs.shape[1] != self.observation_dim:
+            raise ValueError(f"observations must be (N, {self.observation_dim}), got {obs.shape}")
+        n = obs.shape[0]
+        queue = getattr(self, "_batched_actions", None)
+        if queue is None or queue.shape[0] != n or self._batched_cursor >= queue.shape[1]:
+            device = self.diffusion.betas.device
+            mean = torch.as_tensor(self.normalizer.obs_mean, dtype=torch.float32, device=device)
+            std = torch.as_tensor(self.normalizer.obs_std, dtype=torch.float32, device=device)
+            a_mean = torch.as_tensor(self.normalizer.action_mean, dtype=torch.float32, device=device)
+            a_std = torch.as_tensor(self.normalizer.action_std, dtype=torch.float32, device=device)
+            start = torch.zeros(n, self.transition_dim, device=device)
+            start[:, :self.observation_dim] = (torch.from_numpy(obs).to(device) - mean) / std
+            plans = self.sample_loop(batch_size=n, conditions={0: start}, verbose=False)
+            keep = min(self.action_horizon + 1, self.horizon)
+            lo, hi = self.observation_dim, self.observation_dim + self.action_dim
+            self._batched_actions = (plans[:, :keep, lo:hi] * a_std + a_mean).cpu().numpy()
+            self._batched_cursor = 0
+        out = self._batched_actions[:, self._batched_cursor].copy()
+        self._batched_cursor += 1
+        return out
+
+
 class MPCPolicy(GuidedPolicy):
     """Plan once, execute ``action_horizon`` actions, replan (policies.py:226-240)."""
 

@@ -341,3 +341,31 @@ def test_unsupported_architectures_are_refused_with_a_message(dev):
         diff = GaussianDiffusion(unet, H, 4, 2, n_timesteps=10).to(dev)
         with pytest.raises(DadError):
             diff.model(torch.zeros(1, H, 6, device=dev), 0)
+
+
+def test_batched_get_actions_matches_per_env_oracle(dev):
+    """N environments in one loop with per-row conditions: plans equal the oracle's loop with the
+    same (N, td) condition, and the FIFO semantics equal N single-environment policies."""
+    from dynamics_aware_diffusion_amd import GuidedPolicy
+    from dynamics_aware_diffusion_amd.utils import synth
+    from tests.test_hip_parity import injected_noise
+    net, T, N, ah = "tiny", 20, 5, 2
+    diff = build(net, T, "cosine", dev)
+    norm = cases.NormalizerStub(4, 2)
+    obs = synth.normal_like(67, "batched.obs", (N, 4))
+    noise = synth.normal_like(67, "batched.noise", (T + 1, N, 32, 6))
+    pol = GuidedPolicy(diff, norm, action_horizon=ah)
+    with injected_noise(noise, dev):
+        first = pol.get_actions(obs)
+    served = [first] + [pol.get_actions(obs) for _ in range(ah)]          # from the queue
+    cond = np.zeros((N, 6), np.float32)
+    cond[:, :4] = norm.normalize_observations(obs)
+    want = orc.sample_loop(net_weights_torch(net), orc.schedule_buffers("cosine", T),
+                           torch.from_numpy(noise), T, {0: torch.from_numpy(cond)}).numpy()
+    for k, got in enumerate(served):
+        ref = want[:, k, 4:6] * norm.action_std + norm.action_mean
+        assert got.shape == (N, 2)
+        assert max_abs(got, ref) <= TOL_LOOP, k
+    assert pol._batched_cursor == ah + 1                                  # queue exhausted: replan next
+    with pytest.raises(ValueError):
+        pol.get_actions(np.zeros((N, 3), np.float32))
