@@ -559,6 +559,11 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.chunks_per_slice = sp.chunks_per_slice;
     p.slab = ws + m->plan.floats_per_sample * (long)batch;     // scratch behind the activations
     p.counters = m->d_counters;
+    static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;     // tuning aid
+    if (trace)
+        fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d tile=%d (%dx%d SK%d) kslices=%d\n", op.name.c_str(),
+                batch, op.M, op.taps, op.cin0 + op.cin1, op.Lout, cfg, kTiles[cfg].BM, kTiles[cfg].BN,
+                kTiles[cfg].SK, sp.kslices);
 #ifdef DAD_STAMPS
     p.stamps = g_stamps ? g_stamps + (size_t)(&op - &m->plan.convs[0]) * 4096 * 8 : nullptr;
 #endif
