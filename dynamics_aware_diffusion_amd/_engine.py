@@ -17,7 +17,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DAD_LIB") or os.path.join(_HERE, "libdad_hip.so")
 
 DAD_MAX_LEVELS = 8
-DAD_E_RANGE = -5
 
 
 class DadCfg(C.Structure):
@@ -105,11 +104,9 @@ class DadError(RuntimeError):
 
 def _check(lib, rc: int) -> None:
     if rc != 0:
-        msg = lib.dad_last_error().decode("utf-8", "replace")
-        if rc == DAD_E_RANGE:
-            # the reference raises RuntimeError from gather here (diffusion.py:28)
-            raise DadError(rc, msg)
-        raise DadError(rc, msg)
+        # DadError is a RuntimeError: DAD_E_RANGE (timestep outside the schedule) therefore surfaces
+        # as the same exception type the reference's gather raises (diffusion.py:28)
+        raise DadError(rc, lib.dad_last_error().decode("utf-8", "replace"))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -511,10 +511,16 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef DAD_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc2, 0, 0, 0);
+#ifdef DAD_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             ca = na;
             cb = nb;

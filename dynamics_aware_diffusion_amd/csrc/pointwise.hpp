@@ -13,8 +13,6 @@
 namespace dad {
 
 // ------------------------------------------------------------------------------ Philox
-struct PhiloxKey { uint32_t k0, k1; };
-
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

@@ -119,7 +119,10 @@ int dad_denoise_step(dad_model* m, float* x, int32_t t, int32_t batch, const dad
  * (draw id of iteration j is j+1; draw 0 is reserved for x_T, see dad_fill_normal).
  * proj: optional projection applied after every step (README semantics; the shipped
  * reference never calls it — SURVEY.md F5), alphas[n_steps] indexed by t on the HOST.
- * use_graph != 0 replays a cached hipGraph of the whole loop (pointers must be stable). */
+ * use_graph != 0 replays a cached hipGraph of the whole loop: every pointer argument and
+ * (n_steps, batch, row_offset) are frozen in the capture, so callers keep them stable (a new
+ * combination is captured once; at most 16 graphs are cached).  The Philox seed is NOT frozen:
+ * it is written to device memory ahead of each replay. */
 typedef struct dad_project_args {
     const float* P;         /* (D,D) device, D = (H+1)*n + H*m, row-major             */
     const float* obs_mean;  /* device (od) */
