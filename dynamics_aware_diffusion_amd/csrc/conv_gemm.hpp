@@ -221,10 +221,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
                            : XF + (tm * 32 + l32) * KP + 4 * h;
     const int bswz = ((tm * 32 + l32) >> SWZ_SHIFT) & SWZ_MASK;   // (tap*BM adds 0 mod the mask)
 
-    // two independent accumulation chains per wave (even / odd k-steps), summed in the epilogue
-    f32x16 acc, acc2;
+    // four independent accumulation chains per wave (one per k-step of a unit), summed pairwise in
+    // the epilogue: 4x shorter fp32 chains than a single accumulator (K reaches 20480 on the wide
+    // nets), at no cost in matrix-pipe time
+    f32x16 acc, acc2, acc3, acc4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; acc3[r] = 0.0f; acc4[r] = 0.0f; }
 
     const int cin = p.cin0 + p.cin1;
     const int c_begin = kb * p.chunks_per_slice;
@@ -516,8 +518,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #endif
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc3, 0, 0, 0);
+            acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc4, 0, 0, 0);
 #ifdef DAD_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     DAD_STAMP(2);
     DAD_CLOCK(7);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
 
     // ---- epilogue ---------------------------------------------------------------------------
     // 1. every wave drops its accumulators into its split-K copy of the tile E[ks][n][m] (LDS);

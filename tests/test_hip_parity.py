@@ -3,9 +3,10 @@ vectors of the real reference and against the CPU oracle on the same seeded inpu
 
 Tolerances (fp32, stated per SURVEY.md §8(c)): the reference's own fp32-vs-fp64 distance is
 ~1.1e-6 for one U-Net forward and ~1.6e-6 for a full loop.  Gates:
-    single forward / single step  <= 2e-5 abs
-    full loop (T <= 100)          <= 1e-4 abs
-and "HIP is no farther from the fp64 truth than 4x the fp32 reference is (+1e-6)".
+    single forward / single step  <= 5e-6 abs   (measured <= 2e-6 on all five architectures)
+    full loop (T <= 100)          <= 2e-5 abs   (measured <= 6e-6)
+and "HIP is no farther from the fp64 truth than 2x the fp32 reference is (+5e-7)"
+(measured 0.6x - 1.15x: four accumulation chains per wave keep the fp32 sums short).
 """
 import contextlib
 
@@ -18,8 +19,8 @@ from tests.util import as_torch, golden, max_abs
 
 pytestmark = pytest.mark.gpu
 
-TOL_STEP = 2e-5
-TOL_LOOP = 1e-4
+TOL_STEP = 5e-6
+TOL_LOOP = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -109,7 +110,7 @@ def test_unet_forward_vs_reference(case, dev):
     ref64 = max_abs(g["eps"], g["eps_fp64"])
     print(f"{name}: |hip-ref32|={err32:.2e} |hip-fp64|={err64:.2e} |ref32-fp64|={ref64:.2e}")
     assert err32 <= TOL_STEP
-    assert err64 <= 4 * ref64 + 1e-6
+    assert err64 <= 2 * ref64 + 5e-7
 
 
 @pytest.mark.parametrize("case", cases.LOOP_CASES, ids=lambda c: c[0])
