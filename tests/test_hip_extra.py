@@ -79,6 +79,19 @@ def test_wide_group_tiles_on_big_architectures(dev):
         assert max_abs(got, g["eps"]) <= TOL_STEP
 
 
+@pytest.mark.parametrize("net", ["halfcheetah", "door"])
+def test_wide_nets_at_a_ragged_multi_tile_batch(net, dev):
+    """B = 33 on the wide nets: several N tiles per layer (the last one partly empty), 128- and
+    256-channel GroupNorm tiles, grid split-K on the deepest levels — against the oracle."""
+    from dynamics_aware_diffusion_amd.utils import synth
+    diff = build(net, cases.NETS[net][4], "cosine", dev)
+    B, t = 33, 321
+    x = torch.from_numpy(synth.normal_like(68, f"wide.{net}", (B, 32, diff.transition_dim)))
+    want = _oracle_eps(net, x, t).numpy()
+    got = diff.model(x.to(dev), t).cpu().numpy()
+    assert max_abs(got, want) <= TOL_STEP
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 7, 17, 65])
 def test_ragged_batches_match_oracle(B, dev):
     from dynamics_aware_diffusion_amd.utils import synth
