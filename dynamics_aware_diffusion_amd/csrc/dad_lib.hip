@@ -104,6 +104,7 @@ struct GraphKey {
     const void* x; const void* noise; const void* cond; const void* ws; const void* P;
     int n_steps, batch, cond_per_row, pad_ = 0;
     uint64_t row_offset;
+    uint64_t alpha_hash;      // projection strengths are baked into the captured launches
     bool operator<(const GraphKey& o) const {
         return std::memcmp(this, &o, sizeof(GraphKey)) < 0;
     }
@@ -510,7 +511,8 @@ SplitPlan plan_split(const ConvOp& op, int cfg, int batch) {
     const int nchunks = (op.cin0 + op.cin1 + kc - 1) / kc;      // chunks holding real channels
     SplitPlan sp{1, nchunks, 0};
     if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
-    int want = (int)((256 + tiles - 1) / tiles);
+    static const int target = getenv("DAD_SPLIT_TARGET") ? atoi(getenv("DAD_SPLIT_TARGET")) : 256;   // tuning aid
+    int want = (int)((target + tiles - 1) / tiles);
     if (want > nchunks) want = nchunks;
     if (want < 2) return sp;
     sp.chunks_per_slice = (nchunks + want - 1) / want;
@@ -924,6 +926,15 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     key.P = proj ? proj->P : nullptr;
     key.n_steps = n_steps; key.batch = batch; key.cond_per_row = cond_per_row;
     key.row_offset = row_offset;
+    if (proj) {
+        uint64_t hsh = 1469598103934665603ull;            // FNV-1a over the per-step alphas
+        for (int i = 0; i < n_steps; ++i) {
+            uint32_t bits;
+            std::memcpy(&bits, &proj_alphas_host[i], 4);
+            hsh = (hsh ^ bits) * 1099511628211ull;
+        }
+        key.alpha_hash = hsh;
+    }
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         if (m->graphs.size() >= 16) {                 // bounded cache: drop everything, re-capture
