@@ -21,8 +21,10 @@
 //   * SK waves share one 32x32 output tile and split the K units between them (intra-block
 //     split-K): at batch 256 a layer has only ~1 output tile per SIMD, the second wave per
 //     SIMD is what hides LDS/barrier latency.  Partial sums meet in the LDS epilogue tile.
-//   * a transposed conv (k=4, s=2, p=1) runs as a 3-tap conv with M = 2*C_out columns
-//     (even-phase columns, then odd-phase; unused taps are zero) and an interleaving store.
+//   * a transposed conv (k=4, s=2, p=1) runs as a 2-tap conv with M = 2*C_out columns: even
+//     outputs y[2j] = W3 x[j-1] + W1 x[j] (columns [0, C_out)), odd outputs
+//     y[2j+1] = W2 x[j] + W0 x[j+1] (columns [C_out, 2 C_out)); the tile's phase shifts the LDS
+//     row base by one, the store interleaves the two phases.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -209,7 +211,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 
     // A operand (activations): lane's GEMM row n -> LDS row of tap 0
     const int n_loc = tn * 32 + l32;
-    const int arow = ((n_loc >> p.lshift) * SEG + (n_loc & (Lout - 1)) * STRIDE) * KP + 4 * h;
+    // Transposed conv as two 2-tap phases: even outputs read positions (l-1, l), odd outputs
+    // (l, l+1); the M tile's phase shifts the first row by one.
+    const int phase_shift = (TAPS == 2 && p.interleave && m0 >= (p.M >> 1)) ? 1 : 0;
+    const int arow = ((n_loc >> p.lshift) * SEG + (n_loc & (Lout - 1)) * STRIDE + phase_shift) * KP + 4 * h;
     // B operand (weights): lane's output channel
     // LDS-DMA writes 64 lanes x 16 B linearly, so W rows cannot be padded; bank conflicts of the
     // ds_read_b128 are removed by XOR-swizzling the 16-B slot inside a row with the row index

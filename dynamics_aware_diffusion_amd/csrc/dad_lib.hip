@@ -203,7 +203,7 @@ int build_plan(dad_model* m) {
             case CONV_DOWN: op.taps = 3; op.stride = 2; op.M = cout; op.Lout = Lin / 2;
                 expect(m, name + ".weight", {cout, cin, 3});
                 op.flops_per_sample = 2.0 * cout * cin * 3 * (Lin / 2); break;
-            case CONV_UP: op.taps = 3; op.stride = 1; op.M = 2 * cout; op.Lout = Lin;
+            case CONV_UP: op.taps = 2; op.stride = 1; op.M = 2 * cout; op.Lout = Lin;
                 expect(m, name + ".weight", {cin, cout, 4});
                 op.flops_per_sample = 2.0 * cout * cin * 4 * Lin; break;   // algorithmic
         }
@@ -334,22 +334,23 @@ std::vector<float> pack_conv(const HostTensor& w, int cin_pad, int taps, int kc)
 // ConvTranspose1d weight (ci, co, 4), stride 2, pad 1:
 //   y[co, 2j]   = sum_ci W[ci,co,3] x[ci,j-1] + W[ci,co,1] x[ci,j]
 //   y[co, 2j+1] = sum_ci W[ci,co,2] x[ci,j]   + W[ci,co,0] x[ci,j+1]
-// packed as a 3-tap (offsets -1,0,+1) conv with M = 2*co columns: [0,co) even phase,
-// [co,2co) odd phase.
+// packed as a 2-tap conv with M = 2*co columns: columns [0,co) are the even phase (taps at
+// positions j-1, j), columns [co,2co) the odd phase (taps at j, j+1 — the kernel shifts the row
+// base by one for tiles of that half).
 std::vector<float> pack_convT(const HostTensor& w, int cin_pad, int kc) {
     const int ci = (int)w.shape[0], co = (int)w.shape[1];
     const int M = 2 * co;
-    std::vector<float> out((size_t)cin_pad * 3 * M, 0.0f);
+    std::vector<float> out((size_t)cin_pad * 2 * M, 0.0f);
     auto at = [&](int i, int o, int kk) { return w.data[((size_t)i * co + o) * 4 + kk]; };
     for (int i = 0; i < ci; ++i)
         for (int o = 0; o < co; ++o) {
             auto slot = [&](int tap, int m) -> float& {
-                return out[(((size_t)(i / kc) * 3 + tap) * M + m) * kc + (i % kc)];
+                return out[(((size_t)(i / kc) * 2 + tap) * M + m) * kc + (i % kc)];
             };
             slot(0, o) = at(i, o, 3);
             slot(1, o) = at(i, o, 1);
-            slot(1, co + o) = at(i, o, 2);
-            slot(2, co + o) = at(i, o, 0);
+            slot(0, co + o) = at(i, o, 2);
+            slot(1, co + o) = at(i, o, 0);
         }
     return out;
 }
@@ -435,7 +436,7 @@ hipError_t raise_lds_limit_cfg() {
     hipError_t e;
     if ((e = raise_lds_limit<CFG, 5, 1>()) != hipSuccess) return e;
     if ((e = raise_lds_limit<CFG, 3, 2>()) != hipSuccess) return e;
-    if ((e = raise_lds_limit<CFG, 3, 1>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit<CFG, 2, 1>()) != hipSuccess) return e;
     return raise_lds_limit<CFG, 1, 1>();
 }
 int configure_kernels() {
@@ -461,7 +462,7 @@ template <int CFG>
 int launch_conv_cfg(ConvParams& p, int taps, int stride, hipStream_t st) {
     if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1>(p, st);
     if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2>(p, st);
-    if (taps == 3 && stride == 1) return launch_conv_t<CFG, 3, 1>(p, st);
+    if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1>(p, st);
     if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1>(p, st);
     return fail(DAD_E_INVALID, "unsupported conv taps=%d stride=%d", taps, stride);
 }
