@@ -56,6 +56,8 @@ constexpr bool kWDma = DAD_W_DMA != 0;
 #define DAD_PSTAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && DAD_LBID < 4096) p.stamps[DAD_LBID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #undef DAD_STAMP
 #define DAD_STAMP(i) do { if ((i) == 0) DAD_PSTAMP(0); } while (0)
+#undef DAD_CLOCK
+#define DAD_CLOCK(i) do {} while (0)
 #else
 #define DAD_PSTAMP(i) do {} while (0)
 #endif
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         x_q4[i] = q * 4;
         x_loff[i] = e < xrows_real * KQ ? (s * SEG + PAD + l) * KP + q * 4 : -1;
     }
+    DAD_PSTAMP(6);
     const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
     // LDS-DMA descriptors of this wave: instruction q moves the 1 KiB [q*256, q*256+256) floats of
     // the W image; lane -> (row, physical slot) -> swizzled logical slot -> packed global address.
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         res4[k] = (p.res != nullptr && !p.interleave && eoff[k] >= 0)                            \
                       ? *reinterpret_cast<const float4*>(p.res + eoff[k]) : zero4;               \
     }
+    DAD_PSTAMP(7);
     load_stage(c_begin);                   // first global loads fly while LDS is being zeroed
     if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }   // younger than the stage loads: not waited with them
     DAD_PSTAMP(1);

@@ -127,6 +127,11 @@ struct dad_model {
     uint64_t* d_rng = nullptr;
     unsigned* d_counters = nullptr;   // split-K arrival tickets (zero between launches)
     std::vector<void*> owned;         // every hipMalloc to free
+    // All parameters, tables and flags live in ONE device allocation: a conv launch touches a
+    // handful of pages instead of one page per tensor (cold address translations used to cost
+    // ~1 us at the start of every kernel).
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -355,13 +360,43 @@ std::vector<float> pack_convT(const HostTensor& w, int cin_pad, int kc) {
     return out;
 }
 
+int arena_alloc(dad_model* m, size_t bytes, void** out) {
+    const size_t aligned = (bytes + 255) / 256 * 256;
+    if (m->arena_used + aligned > m->arena_cap)
+        return fail(DAD_E_STATE, "parameter arena exhausted (%zu + %zu > %zu)", m->arena_used, aligned,
+                    m->arena_cap);
+    *out = m->arena + m->arena_used;
+    m->arena_used += aligned;
+    return DAD_OK;
+}
+
 int upload(dad_model* m, const std::vector<float>& host, float** dev) {
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, std::max<size_t>(host.size(), 1) * sizeof(float)));
-    m->owned.push_back(p);
+    const int rc = arena_alloc(m, std::max<size_t>(host.size(), 1) * sizeof(float), &p);
+    if (rc != DAD_OK) return rc;
     HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     *dev = (float*)p;
     return DAD_OK;
+}
+
+// Bytes the arena must hold: packed weights, norms, tables, time-MLP weights, flags.
+size_t arena_bytes_needed(const dad_model* m) {
+    const dad_cfg& c = m->cfg;
+    size_t floats = 0, allocs = 0;
+    auto add = [&](size_t n) { floats += n + 64; ++allocs; };
+    for (const ConvOp& op : m->plan.convs) {
+        add((size_t)op.cin_pad * op.taps * op.M);
+        add(op.M);
+        if (!op.norm.empty()) { add(op.cout); add(op.cout); }
+        if (op.temb_off >= 0) { add((size_t)op.cout * c.time_dim); add(op.cout); }
+    }
+    add((size_t)c.transition_dim * c.dim); add(c.transition_dim);
+    const size_t T = c.n_timesteps;
+    add(T * c.dim); add(T * 4 * c.time_dim); add(T * c.time_dim);
+    add(T * std::max(1, m->plan.temb_width));
+    add((size_t)4 * c.time_dim * c.dim); add(4 * c.time_dim);
+    add((size_t)c.time_dim * 4 * c.time_dim); add(c.time_dim);
+    return floats * sizeof(float) + allocs * 256 + kMaxSplitTiles * sizeof(unsigned) + (1 << 16);
 }
 
 void free_device(dad_model* m) {
@@ -369,6 +404,8 @@ void free_device(dad_model* m) {
     m->graphs.clear();
     for (void* p : m->owned) (void)hipFree(p);
     m->owned.clear();
+    m->arena = nullptr;
+    m->arena_cap = m->arena_used = 0;
     m->d_temb_table = nullptr;
     m->d_final_w = m->d_final_b = nullptr;
     m->d_rng = nullptr;
@@ -771,6 +808,14 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     }
     free_device(m);
     const dad_cfg& c = m->cfg;
+    {
+        void* a = nullptr;
+        m->arena_cap = arena_bytes_needed(m);
+        HIP_TRY(hipMalloc(&a, m->arena_cap));
+        m->owned.push_back(a);
+        m->arena = (char*)a;
+        m->arena_used = 0;
+    }
 
     for (ConvOp& op : m->plan.convs) {
         const HostTensor& w = m->raw[op.name + ".weight"];
@@ -833,12 +878,10 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
                          m->plan.temb_width, 1)) != DAD_OK) return rc;
     }
     void* rng = nullptr;
-    HIP_TRY(hipMalloc(&rng, 64));
-    m->owned.push_back(rng);
+    if ((rc = arena_alloc(m, 64, &rng)) != DAD_OK) return rc;
     m->d_rng = (uint64_t*)rng;
     void* cnt = nullptr;
-    HIP_TRY(hipMalloc(&cnt, kMaxSplitTiles * sizeof(unsigned)));
-    m->owned.push_back(cnt);
+    if ((rc = arena_alloc(m, kMaxSplitTiles * sizeof(unsigned), &cnt)) != DAD_OK) return rc;
     HIP_TRY(hipMemsetAsync(cnt, 0, kMaxSplitTiles * sizeof(unsigned), st));
     m->d_counters = (unsigned*)cnt;
     HIP_TRY(hipStreamSynchronize(st));
