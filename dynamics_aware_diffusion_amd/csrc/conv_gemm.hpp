@@ -136,6 +136,16 @@ __device__ __forceinline__ float rows_sum(float v, int width, int lane) {
     return lane < 32 ? lo : hi;
 }
 
+// 16-byte load through an explicitly GLOBAL pointer.  A `cond ? *p : zero` on a generic pointer
+// makes hipcc select between addresses and emit flat_load: flat loads count on lgkmcnt as well
+// as vmcnt, so the next LDS/scalar wait drains them (measured: +2 us in every kernel prologue).
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    const f4 v = *reinterpret_cast<const __attribute__((address_space(1))) f4*>(
+        (const __attribute__((address_space(1))) float*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform base + lane*16).
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -462,12 +472,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #define DAD_FETCH_PARAMS()                                                                       \
     _Pragma("unroll") for (int k = 0; k < F4PL; ++k) {                                           \
         const int em = m0 + ecol[k];                                                             \
-        bias4[k] = *reinterpret_cast<const float4*>(p.bias + em);                                \
-        gam4[k] = has_gn ? *reinterpret_cast<const float4*>(p.gamma + em) : zero4;               \
-        bet4[k] = has_gn ? *reinterpret_cast<const float4*>(p.beta + em) : zero4;                \
-        temb4[k] = p.temb != nullptr ? *reinterpret_cast<const float4*>(p.temb + em) : zero4;    \
-        res4[k] = (p.res != nullptr && !p.interleave && eoff[k] >= 0)                            \
-                      ? *reinterpret_cast<const float4*>(p.res + eoff[k]) : zero4;               \
+        bias4[k] = ldg4(p.bias + em);                                                            \
+        gam4[k] = zero4; bet4[k] = zero4; temb4[k] = zero4; res4[k] = zero4;                     \
+        if (has_gn) { gam4[k] = ldg4(p.gamma + em); bet4[k] = ldg4(p.beta + em); }               \
+        if (p.temb != nullptr) temb4[k] = ldg4(p.temb + em);                                     \
+        if (p.res != nullptr && !p.interleave && eoff[k] >= 0) res4[k] = ldg4(p.res + eoff[k]);  \
     }
     DAD_PSTAMP(7);
     load_stage(c_begin);                   // first global loads fly while LDS is being zeroed
