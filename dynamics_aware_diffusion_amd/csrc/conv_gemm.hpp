@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int ps = has_gn ? pr >> gpt_sh : 0;          // sample of the pair
     const int pg = has_gn ? pr & ((1 << gpt_sh) - 1) : 0;   // group of the pair
     int erow[F4PL], ecol[F4PL];
-    long eoff[F4PL];
+    int eoff[F4PL];                                    // output offsets fit 31 bits (host-checked)
     float4 bias4[F4PL], gam4[F4PL], bet4[F4PL], temb4[F4PL], res4[F4PL];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -456,11 +456,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int l = erow[k] & (Lout - 1);
         const int em = m0 + ecol[k];
         if (!p.interleave) {
-            eoff[k] = ((long)(s0 + s) * Lout + l) * M + em;
+            eoff[k] = ((s0 + s) * Lout + l) * M + em;
         } else {
             const int half = M >> 1;
             const int phase = em >= half;
-            eoff[k] = ((long)(s0 + s) * (2 * Lout) + 2 * l + phase) * half + (em - phase * half);
+            eoff[k] = ((s0 + s) * (2 * Lout) + 2 * l + phase) * half + (em - phase * half);
         }
         if (s >= nvalid) eoff[k] = -1;
     }

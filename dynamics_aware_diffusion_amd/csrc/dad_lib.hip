@@ -589,6 +589,9 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout; p.lshift = ilog2(op.Lout);
     p.lshift_in = ilog2(op.Lin);
     p.interleave = op.kind == CONV_UP;
+    if ((long)batch * op.Lout * op.M * (op.kind == CONV_UP ? 1 : 1) >= (1L << 31) ||
+        (long)batch * op.Lin * (op.cin0 + op.cin1) >= (1L << 31))
+        return fail(DAD_E_INVALID, "batch %d too large: a layer's activation tensor exceeds 2^31 elements", batch);
     const int cfg = choose_tile(op, batch);
     if (cfg < 0)
         return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
