@@ -18,7 +18,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None   # newest pass wins when runs were merged
 
 
 stats = one("trace/**/*_kernel_stats.csv")
