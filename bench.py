@@ -48,10 +48,11 @@ WORKLOADS = {
 }
 
 
-def build_policy(arch: str, device: torch.device):
+def build_policy(arch: str, device: torch.device, precision: str = "fp32"):
     od, ad, dim, mults, T = synth.ARCHS[arch]
     td = od + ad
     unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet.precision = precision
     state = synth.synth_unet_state(td, dim, mults, seed=0)
     unet.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     diff = GaussianDiffusion(unet, 32, od, ad, n_timesteps=T).to(device)
@@ -111,6 +112,9 @@ def main() -> None:
     ap.add_argument("--workload", default="pointmaze_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
+                    help="conv arithmetic: exact fp32 MFMA, or split-f16 operands (3 f16 MFMAs per "
+                         "product block, fp32 accumulation; same parity gates)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent sampling loops kept in flight on separate HIP streams "
                          "(diagnostic: shows how much of a step is dependency bubbles; the "
@@ -144,7 +148,7 @@ def main() -> None:
     arch, batch, desc = WORKLOADS[args.workload]
     od, ad, dim, mults, T = synth.ARCHS[arch]
     td = od + ad
-    policy, diff, cond, state = build_policy(arch, device)
+    policy, diff, cond, state = build_policy(arch, device, args.precision)
     diff.use_graph = batch <= 32          # small batches are launch-bound: replay one hipGraph
     gathered = torch.empty(world * batch, 32, td, device=device) if world > 1 else None
 
@@ -166,7 +170,7 @@ def main() -> None:
 
     extra = []
     if args.inflight > 1:                     # one policy/engine + stream per loop in flight
-        extra = [(build_policy(arch, device), torch.cuda.Stream(device)) for _ in range(args.inflight - 1)]
+        extra = [(build_policy(arch, device, args.precision), torch.cuda.Stream(device)) for _ in range(args.inflight - 1)]
 
     def run_steps(first: int, count: int):
         out = None
@@ -239,7 +243,7 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "arch": arch, "batch_per_gpu": batch,
                        "global_batch": world * batch, "horizon": 32, "denoise_steps": T,
-                       "rng": "in-kernel philox", "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end", "loops_in_flight": args.inflight},
+                       "rng": "in-kernel philox", "conv_arithmetic": args.precision, "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end", "loops_in_flight": args.inflight},
             "roofline": roof, "cpu_baseline": base,
         }
         print(json.dumps(out))

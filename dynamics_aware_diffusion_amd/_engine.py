@@ -54,6 +54,7 @@ ABI = {
     "dad_model_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p,
                                         C.POINTER(C.c_int64), C.c_int32]),
     "dad_model_load_schedule": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    "dad_model_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_model_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t)]),
     "dad_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -122,6 +123,8 @@ def _require_device(t: torch.Tensor, name: str) -> None:
                            f"contiguous={t.is_contiguous()})")
 
 
+PRECISIONS = {"fp32": 0, "f16x3": 1}      # DAD_PREC_* of include/dad.h
+
 SCHEDULE_KEYS = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
                  "posterior_mean_coef1", "posterior_mean_coef2",
                  "posterior_log_variance_clipped")
@@ -133,7 +136,10 @@ class HipEngine:
     def __init__(self, *, transition_dim: int, dim: int, channels: Sequence[int], horizon: int,
                  n_timesteps: int, time_dim: Optional[int] = None, kernel_size: int = 5,
                  predict_epsilon: bool = True, clip_denoised: bool = True,
-                 device: torch.device | str = "cuda"):
+                 device: torch.device | str = "cuda", precision: str = "fp32"):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+        self.precision = precision
         self.lib = load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -157,6 +163,7 @@ class HipEngine:
         handle = C.c_void_p()
         _check(self.lib, self.lib.dad_model_create(C.byref(cfg), C.byref(handle)))
         self._h = handle
+        _check(self.lib, self.lib.dad_model_set_precision(self._h, PRECISIONS[precision]))
         self._ws: Dict[int, torch.Tensor] = {}
         self._pinned: Dict[tuple, torch.Tensor] = {}
         self.ready = False

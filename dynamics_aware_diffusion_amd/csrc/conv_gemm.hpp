@@ -63,6 +63,34 @@ constexpr bool kWDma = DAD_W_DMA != 0;
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---- split-f16 operands (template parameter X3) ---------------------------------------------
+// An fp32 value v is carried as two halves  v ~= hi + lo * 2^-11,  hi = f16(v),
+// lo = f16((v - hi) * 2^11)  (22 significant bits; the residual is scaled so it stays a normal
+// f16).  A product is then three v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+//     x*w ~= xh*wh  +  2^-11 (xh*wl + xl*wh)          (the dropped xl*wl term is 2^-22 relative)
+// — 3/16 of the matrix-pipe cycles of the exact-fp32 MFMA at the same LDS/HBM bytes (2+2 B per
+// element).  Weights are split on the host at pack time (pre-scaled by a power of two per layer
+// so that small weights stay normal halves), activations while they are staged into LDS.
+// Measured against the fp64 run of the reference this path is as close as the reference's own
+// fp32 arithmetic (tests/test_hip_split.py); value range: |activation| <= 65504 (saturates).
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    const float c = __builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f);
+    hi = (_Float16)c;
+    lo = (_Float16)((c - (float)hi) * 2048.0f);
+}
+__device__ __forceinline__ void split_f16x4(const float4 v, float2& hi, float2& lo) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f16x4 h, l;
+    _Float16 a, b;
+    split_f16(v.x, a, b); h[0] = a; l[0] = b;
+    split_f16(v.y, a, b); h[1] = a; l[1] = b;
+    split_f16(v.z, a, b); h[2] = a; l[2] = b;
+    split_f16(v.w, a, b); h[3] = a; l[3] = b;
+    hi = __builtin_bit_cast(float2, h);
+    lo = __builtin_bit_cast(float2, l);
+}
 
 struct ConvParams {
     const float* src0;   // [B*Lin][cin0]
@@ -87,6 +115,7 @@ struct ConvParams {
     // grid-level split-K (few tiles: small batches, the deepest levels of wide nets)
     int32_t kslices;     // blocks per output tile (1 = off)
     int32_t chunks_per_slice;
+    float c1, c2;        // split-f16 kernels: out = acc_hh * c1 + acc_cross * c2  (2^-s, 2^-s-11)
     float* slab;         // [tiles][kslices][BN*BM] fp32 partial tiles (workspace)
     unsigned* counters;  // [tiles] arrival tickets, zero between launches
 #ifdef DAD_STAMPS
@@ -167,7 +196,7 @@ __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int ta
     return k > epi ? k : epi;
 }
 
-template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED>
+template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED, bool X3 = false>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32(const ConvParams p) {
     constexpr int TMW = BM / 32;                 // wave tiles along M
     constexpr int TNW = BN / 32;                 // wave tiles along N
@@ -176,11 +205,15 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     constexpr int PAD = TAPS / 2;
     constexpr int KP = KC + 4;                   // LDS row stride (floats): 16-B aligned, odd in
                                                  // 16-B units -> conflict-free ds_read_b128
-    constexpr int G = KC / 8;                    // 8-channel groups per chunk
-    constexpr int GW = G / SK;                   // groups each split-K wave owns, per tap
+    constexpr int KU = X3 ? 16 : 8;              // channels per unit: 4 fp32 MFMAs (k=2 each) or
+                                                 // 3 split-f16 MFMAs (k=16); a unit's operands
+                                                 // take KU floats of an LDS row in either format
+    constexpr int G = KC / KU;                   // units per tap per chunk
+    constexpr int GW = G / SK;                   // units each split-K wave owns, per tap
     constexpr int KG = KC < 16 ? KC : 16;        // packing granule of the weights
     constexpr int NSUB = KC / KG;                // packed granules per chunk
-    static_assert(KC % 8 == 0 && G % SK == 0, "K chunk must split evenly over the SK waves");
+    static_assert(KC % KU == 0 && G % SK == 0 && GW >= 1, "K chunk must split evenly over the SK waves");
+    static_assert(!X3 || !kWDma, "split-f16 operands use register staging");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef DAD_ABLATE_NULL
@@ -288,7 +321,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const bool ok = e < xrows_real * KQ && s < nvalid;
         x_grow[i] = ok ? s0 * Lin + row : -1;
         x_q4[i] = q * 4;
-        x_loff[i] = e < xrows_real * KQ ? (s * SEG + PAD + l) * KP + q * 4 : -1;
+        // split-f16 rows: per 16-channel unit [8 floats of hi halves | 8 floats of lo halves]
+        const int qoff = X3 ? (q >> 2) * 16 + (q & 3) * 2 : q * 4;
+        x_loff[i] = e < xrows_real * KQ ? (s * SEG + PAD + l) * KP + qoff : -1;
     }
     DAD_PSTAMP(6);
     const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
@@ -382,8 +417,17 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
                     *reinterpret_cast<float4*>(&smem[base + w_loff[i]]) = wreg[i];
         }
 #pragma unroll
-        for (int i = 0; i < X_PER_T; ++i)
-            if (x_loff[i] >= 0) *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = xreg[i];
+        for (int i = 0; i < X_PER_T; ++i) {
+            if (x_loff[i] < 0) continue;
+            if constexpr (X3) {
+                float2 hi, lo;
+                split_f16x4(xreg[i], hi, lo);
+                *reinterpret_cast<float2*>(&smem[base + x_loff[i]]) = hi;
+                *reinterpret_cast<float2*>(&smem[base + x_loff[i] + 8]) = lo;
+            } else {
+                *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = xreg[i];
+            }
+        }
     };
 
     // ---- main loop -------------------------------------------------------------------------
@@ -397,12 +441,16 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     //     fragments of the next chunk are fetched behind the barrier while those MFMAs run, so
     //     the matrix pipe does not drain at the barrier.
     constexpr int UW = TAPS * GW;                       // units (4 MFMAs each) per wave per chunk
-    const int koff = ks * (GW * 8);                     // this wave's channel groups in a chunk
+    const int koff = ks * (GW * KU);                    // this wave's units in a chunk
     const int afrag = arow + koff;
     const int bfrag = brow + koff;
     auto frag_a = [&](int stage, int u) -> float4 {
         const int tap = u / GW, gw = u - tap * GW;
-        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * 8]);
+        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * KU]);
+    };
+    auto frag_a_lo = [&](int stage, int u) -> float4 {      // split-f16: the residual halves
+        const int tap = u / GW, gw = u - tap * GW;
+        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * KU + 8]);
     };
     int bsl[GW];                                        // swizzled slot offsets (floats), per group
 #pragma unroll
@@ -412,7 +460,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         if constexpr (kWDma)
             return *reinterpret_cast<const float4*>(&smem[stage * STAGE + brow + tap * BM * WP + bsl[gw]]);
         else
-            return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * 8]);
+            return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * KU]);
+    };
+    auto frag_b_lo = [&](int stage, int u) -> float4 {
+        const int tap = u / GW, gw = u - tap * GW;
+        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * KU + 8]);
     };
 
     // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
@@ -497,6 +549,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     if constexpr (kWDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first W images landed
     __syncthreads();
     DAD_PSTAMP(5);
+    if constexpr (!X3) {
     float4 ca = frag_a(0, 0), cb = frag_b(0, 0);
     DAD_STAMP(1);
     DAD_CLOCK(6);
@@ -546,11 +599,48 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             cb = nb;
         }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
+    } else {
+    // split-f16 operands: a unit is 16 channels = 3 MFMAs (hi*hi into acc, the two cross terms
+    // into acc2 / acc3, which carry a factor 2^11); same pipeline shape as above.
+    float4 ah = frag_a(0, 0), al = frag_a_lo(0, 0), bh = frag_b(0, 0), bl = frag_b_lo(0, 0);
+    DAD_STAMP(1);
+    DAD_CLOCK(6);
+    for (int ch = c_begin; ch < nchunks; ++ch) {
+        const int cur = (ch - c_begin) & 1;
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            float4 nah = ah, nal = al, nbh = bh, nbl = bl;
+            if (u + 1 < UW) {
+                nah = frag_a(cur, u + 1); nbh = frag_b(cur, u + 1);
+                nal = frag_a_lo(cur, u + 1); nbl = frag_b_lo(cur, u + 1);
+            } else {
+                if (ch + 1 < nchunks) store_stage(cur ^ 1);
+                __syncthreads();
+                if (ch + 2 < nchunks) load_stage(ch + 2);
+                if (ch + 1 < nchunks) {
+                    nah = frag_a(cur ^ 1, 0); nbh = frag_b(cur ^ 1, 0);
+                    nal = frag_a_lo(cur ^ 1, 0); nbl = frag_b_lo(cur ^ 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),
+                                                         __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),
+                                                          __builtin_bit_cast(f16x8, bl), acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al),
+                                                          __builtin_bit_cast(f16x8, bh), acc3, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ah = nah; al = nal; bh = nbh; bl = nbl;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc[r] * p.c1 + (acc2[r] + acc3[r]) * p.c2;
+    }
     __syncthreads();                       // all MFMAs retired before the stage memory is reused
     DAD_STAMP(2);
     DAD_CLOCK(7);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
 
     // ---- epilogue ---------------------------------------------------------------------------
     // 1. every wave drops its accumulators into its split-K copy of the tile E[ks][n][m] (LDS);

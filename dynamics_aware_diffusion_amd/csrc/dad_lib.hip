@@ -63,6 +63,8 @@ struct ConvOp {
     int src0, src1, dst, res;
     int temb_off;            // offset into the per-t table, or -1
     int kc = 16;             // K chunk the weights are packed for (8 when C_out/8 == 256)
+    bool x3 = false;         // weights packed as split-f16 images (dad_model_set_precision)
+    float c1 = 1.0f, c2 = 0.0f;   // x3: output scales 2^-s and 2^-(s+11)
     // device tensors (owned by the model)
     float* d_w = nullptr;
     float* d_bias = nullptr;
@@ -118,6 +120,7 @@ struct dad_model {
     std::map<std::string, std::vector<int64_t>> expected;     // key -> shape
     Plan plan;
     bool finalized = false;
+    int precision = DAD_PREC_FP32;                             // dad_model_set_precision
     std::vector<float> sched[5];                               // host schedule scalars
     bool have_sched = false;
     // device
@@ -193,7 +196,7 @@ int build_plan(dad_model* m) {
         op.name = name; op.norm = norm; op.kind = kind;
         op.cin0 = cin0; op.cin1 = cin1;
         op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
-        const int padto = op.kc == 8 ? 8 : (kind == CONV_1X1 ? 128 : 32);   // deepest K chunk of its kernels
+        const int padto = op.kc == 8 ? 8 : (kind == CONV_1X1 ? 128 : 64);   // deepest K chunk of its kernels
         op.cin_pad = (cin0 + cin1 + padto - 1) / padto * padto;
         op.cout = cout; op.src0 = src0; op.src1 = src1; op.dst = dst; op.res = res;
         op.temb_off = toff; op.Lin = Lin;
@@ -360,6 +363,41 @@ std::vector<float> pack_convT(const HostTensor& w, int cin_pad, int kc) {
     return out;
 }
 
+// Split-f16 image of a packed weight tensor (granules of 16 input channels):
+//   [8 words: 16 hi halves | 8 words: 16 lo halves],  w * 2^s ~= hi + lo * 2^-11,
+// s chosen per layer so the largest weight lands in [2^9, 2^10) and small ones stay normal halves.
+// The kernel reads the words as the 32x32x16 f16 MFMA operand (conv_gemm.hpp, X3).
+uint16_t f16_bits(float v) {
+    const _Float16 h = (_Float16)v;       // round to nearest even
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+int split_f16_image(std::vector<float>& packed) {
+    float amax = 0.0f;
+    for (float v : packed) amax = std::max(amax, std::fabs(v));
+    int s = 0;
+    if (amax > 0.0f && std::isfinite(amax)) {
+        int e;
+        std::frexp(amax, &e);             // amax = f * 2^e, f in [0.5, 1)
+        s = 10 - e;                       // amax * 2^s in [2^9, 2^10)
+    }
+    s = std::max(-100, std::min(100, s));
+    const float up = std::ldexp(1.0f, s);
+    for (size_t g = 0; g + 16 <= packed.size(); g += 16) {
+        uint16_t hi[16], lo[16];
+        for (int j = 0; j < 16; ++j) {
+            const float v = packed[g + j] * up;
+            const _Float16 h = (_Float16)v;
+            hi[j] = f16_bits(v);
+            lo[j] = f16_bits((v - (float)h) * 2048.0f);
+        }
+        std::memcpy(&packed[g], hi, 32);
+        std::memcpy(&packed[g + 8], lo, 32);
+    }
+    return s;
+}
+
 int arena_alloc(dad_model* m, size_t bytes, void** out) {
     const size_t aligned = (bytes + 255) / 256 * 256;
     if (m->arena_used + aligned > m->arena_cap)
@@ -426,22 +464,25 @@ template <> struct Tile<7> { static constexpr int BM = 64, BN = 64, SK = 2, KC =
 
 // 1x1 convs have one (tap, group) unit per 8 channels: a deep K chunk keeps enough MFMAs between
 // barriers (128 channels; 64 for the 128-row tile, whose stage would not fit LDS twice).
-constexpr int eff_kc(int cfg_kc, int bm, int taps) {
-    return (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128) : cfg_kc;
+// Split-f16 kernels consume 16 channels per unit: the chunk must give every split-K wave a unit.
+constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false) {
+    return (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128)
+           : (x3 && cfg_kc < 16 * sk)  ? 16 * sk
+                                       : cfg_kc;
 }
 
-template <int CFG, int TAPS, int STRIDE>
+template <int CFG, int TAPS, int STRIDE, bool X3>
 int launch_conv_t(ConvParams& p, hipStream_t st) {
     using T = Tile<CFG>;
-    constexpr int KC = eff_kc(T::KC, T::BM, TAPS);
+    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3);
     const int cin = p.cin0 + p.cin1;
     const bool ragged = (p.cin0 & 3) != 0 || (p.cin1 & 3) != 0 || p.cin0 % KC != 0 || cin % KC != 0;
     if (ragged && !(STRIDE == 1 && (TAPS == 5 || TAPS == 1)))
         return fail(DAD_E_INVALID, "channel count %d+%d needs the general staging path, which exists "
                     "for stride-1 5-tap and 1x1 convs only", p.cin0, p.cin1);
     auto kern = (ragged && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
-                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true>
-                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false>;
+                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true, X3>
+                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3>;
     const size_t lds = dad::conv_lds_floats(T::BM, T::BN, KC, TAPS, p.Lin, p.Lout, T::SK) * sizeof(float);
     const int spt = T::BN / p.Lout;
     p.ntiles_n = (p.B + spt - 1) / spt;
@@ -454,27 +495,34 @@ int launch_conv_t(ConvParams& p, hipStream_t st) {
 
 // Every kernel may use up to the full 160 KiB of LDS; raise the dynamic-LDS limit once
 // (not lazily, so that nothing but launches happens under hipGraph capture).
-template <int CFG, int TAPS, int STRIDE>
+template <int CFG, int TAPS, int STRIDE, bool X3>
 hipError_t raise_lds_limit() {
     using T = Tile<CFG>;
-    constexpr int KC = eff_kc(T::KC, T::BM, TAPS);
+    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3);
     hipError_t e = hipFuncSetAttribute(
-        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false>,
+        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3>,
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     if (STRIDE == 1 && (TAPS == 5 || TAPS == 1))
         e = hipFuncSetAttribute(
-            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true>,
+            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true, X3>,
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 template <int CFG>
 hipError_t raise_lds_limit_cfg() {
     hipError_t e;
-    if ((e = raise_lds_limit<CFG, 5, 1>()) != hipSuccess) return e;
-    if ((e = raise_lds_limit<CFG, 3, 2>()) != hipSuccess) return e;
-    if ((e = raise_lds_limit<CFG, 2, 1>()) != hipSuccess) return e;
-    return raise_lds_limit<CFG, 1, 1>();
+    if ((e = raise_lds_limit<CFG, 5, 1, false>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit<CFG, 3, 2, false>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit<CFG, 2, 1, false>()) != hipSuccess) return e;
+    if ((e = raise_lds_limit<CFG, 1, 1, false>()) != hipSuccess) return e;
+    if constexpr (Tile<CFG>::KC >= 16) {      // split-f16 variants (16-channel granules)
+        if ((e = raise_lds_limit<CFG, 5, 1, true>()) != hipSuccess) return e;
+        if ((e = raise_lds_limit<CFG, 3, 2, true>()) != hipSuccess) return e;
+        if ((e = raise_lds_limit<CFG, 2, 1, true>()) != hipSuccess) return e;
+        if ((e = raise_lds_limit<CFG, 1, 1, true>()) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 int configure_kernels() {
     static bool done = false;
@@ -496,11 +544,20 @@ int configure_kernels() {
 }
 
 template <int CFG>
-int launch_conv_cfg(ConvParams& p, int taps, int stride, hipStream_t st) {
-    if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1>(p, st);
-    if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2>(p, st);
-    if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1>(p, st);
-    if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1>(p, st);
+int launch_conv_cfg(ConvParams& p, int taps, int stride, bool x3, hipStream_t st) {
+    if constexpr (Tile<CFG>::KC >= 16) {
+        if (x3) {
+            if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, true>(p, st);
+            if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2, true>(p, st);
+            if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1, true>(p, st);
+            if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1, true>(p, st);
+        }
+    }
+    if (x3) return fail(DAD_E_INVALID, "no split-f16 kernel for tile %d taps=%d stride=%d", CFG, taps, stride);
+    if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, false>(p, st);
+    if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2, false>(p, st);
+    if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1, false>(p, st);
+    if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1, false>(p, st);
     return fail(DAD_E_INVALID, "unsupported conv taps=%d stride=%d", taps, stride);
 }
 
@@ -545,7 +602,7 @@ SplitPlan plan_split(const ConvOp& op, int cfg, int batch) {
     const TileCfg& t = kTiles[cfg];
     const int spt = t.BN / op.Lout;
     const long tiles = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
-    const int kc = eff_kc(t.KC, t.BM, op.taps);
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3);
     const int nchunks = (op.cin0 + op.cin1 + kc - 1) / kc;      // chunks holding real channels
     SplitPlan sp{1, nchunks, 0};
     if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
@@ -602,6 +659,7 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.chunks_per_slice = sp.chunks_per_slice;
     p.slab = ws + m->plan.floats_per_sample * (long)batch;     // scratch behind the activations
     p.counters = m->d_counters;
+    p.c1 = op.c1; p.c2 = op.c2;
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;     // tuning aid
     if (trace)
         fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d tile=%d (%dx%d SK%d) kslices=%d\n", op.name.c_str(),
@@ -612,14 +670,14 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
 #endif
     int rc;
     switch (cfg) {
-        case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, st); break;
-        case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, st); break;
-        case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, st); break;
-        case 3: rc = launch_conv_cfg<3>(p, op.taps, op.stride, st); break;
-        case 4: rc = launch_conv_cfg<4>(p, op.taps, op.stride, st); break;
-        case 5: rc = launch_conv_cfg<5>(p, op.taps, op.stride, st); break;
-        case 6: rc = launch_conv_cfg<6>(p, op.taps, op.stride, st); break;
-        default: rc = launch_conv_cfg<7>(p, op.taps, op.stride, st); break;
+        case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, op.x3, st); break;
+        case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, op.x3, st); break;
+        case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, op.x3, st); break;
+        case 3: rc = launch_conv_cfg<3>(p, op.taps, op.stride, op.x3, st); break;
+        case 4: rc = launch_conv_cfg<4>(p, op.taps, op.stride, op.x3, st); break;
+        case 5: rc = launch_conv_cfg<5>(p, op.taps, op.stride, op.x3, st); break;
+        case 6: rc = launch_conv_cfg<6>(p, op.taps, op.stride, op.x3, st); break;
+        default: rc = launch_conv_cfg<7>(p, op.taps, op.stride, op.x3, st); break;
     }
     return rc;
 }
@@ -798,6 +856,15 @@ int dad_model_load_schedule(dad_model* m, const float* a, const float* b, const 
     return DAD_OK;
 }
 
+int dad_model_set_precision(dad_model* m, int32_t precision) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    if (precision != DAD_PREC_FP32 && precision != DAD_PREC_F16X3)
+        return fail(DAD_E_INVALID, "unknown precision %d (DAD_PREC_FP32 = 0, DAD_PREC_F16X3 = 1)", precision);
+    if (precision != m->precision) m->finalized = false;       // weights must be re-packed
+    m->precision = precision;
+    return DAD_OK;
+}
+
 int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     if (!m) return fail(DAD_E_INVALID, "null model");
     if (!m->have_sched) return fail(DAD_E_STATE, "schedule not loaded");
@@ -825,6 +892,19 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
         const HostTensor& b = m->raw[op.name + ".bias"];
         std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad, op.kc)
                                                        : pack_conv(w, op.cin_pad, op.taps, op.kc);
+        // split-f16 operands where the kernels exist for every tile this layer may get: 16-channel
+        // granules, and for the strided / transposed convs (no general staging path) whole
+        // 64-channel chunks
+        const int cin = op.cin0 + op.cin1;
+        op.x3 = m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
+                (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
+                 ((op.cin0 & 63) == 0 && (cin & 63) == 0));
+        op.c1 = 1.0f; op.c2 = 0.0f;
+        if (op.x3) {
+            const int sh = split_f16_image(packed);
+            op.c1 = std::ldexp(1.0f, -sh);
+            op.c2 = std::ldexp(1.0f, -sh - 11);
+        }
         int rc = upload(m, packed, &op.d_w);
         if (rc != DAD_OK) return rc;
         std::vector<float> bias = b.data;

@@ -62,6 +62,8 @@ class TemporalUnet(nn.Module):
     (diffusion.py:248; guides/policies.py:146).
     """
 
+    default_precision = "fp32"      # what new instances start with (see ``precision`` below)
+
     def __init__(self, transition_dim: int, dim: int = 128,
                  dim_mults: Sequence[int] = (1, 2, 4, 8), kernel_size: int = 5,
                  time_dim: Optional[int] = None):
@@ -76,6 +78,10 @@ class TemporalUnet(nn.Module):
         for key, shape in unet_param_shapes(self.transition_dim, self.dim, self.dim_mults,
                                             self.kernel_size, self.time_dim).items():
             _attach(self, key, nn.Parameter(_default_init(key, shape, fan)))
+        # Conv arithmetic of the engine (include/dad.h DAD_PREC_*): "fp32" = exact fp32 MFMA,
+        # "f16x3" = split-f16 operands, three f16 MFMAs per product, fp32 accumulation; both meet
+        # the same fp32 parity gates.  Changing it re-packs the weights on the next call.
+        self.precision = type(self).default_precision
         # engine state (not part of state_dict)
         self._engine: Optional[HipEngine] = None
         self._engine_sig = None
@@ -99,7 +105,7 @@ class TemporalUnet(nn.Module):
         sched = None
         if self._schedule is not None:
             sched = tuple((k, v.data_ptr(), v._version) for k, v in sorted(self._schedule.items()))
-        return (horizon, str(device), opts, params, sched)
+        return (horizon, str(device), opts, params, sched, self.precision)
 
     def engine(self, horizon: int, device: torch.device) -> HipEngine:
         """Return the engine for (horizon, device), (re)building it if weights, schedule or
@@ -117,7 +123,8 @@ class TemporalUnet(nn.Module):
         eng = HipEngine(transition_dim=self.transition_dim, dim=self.dim, channels=self.channels,
                         horizon=horizon, n_timesteps=T, time_dim=self.time_dim,
                         kernel_size=self.kernel_size, predict_epsilon=opts["predict_epsilon"],
-                        clip_denoised=opts["clip_denoised"], device=device)
+                        clip_denoised=opts["clip_denoised"], device=device,
+                        precision=self.precision)
         if self._schedule is not None:
             sched = self._schedule
         else:

@@ -37,6 +37,14 @@ extern "C" {
 
 #define DAD_MAX_LEVELS 8
 
+/* How the conv GEMMs multiply (dad_model_set_precision).  Both accumulate in fp32 and meet the same
+ * fp32 parity tolerance against the reference (m_diffuser runs F.conv1d in fp32):
+ *   FP32   exact fp32 products on v_mfma_f32_32x32x2_f32 (default);
+ *   F16X3  every fp32 operand carried as two halves (hi + lo*2^-11, 22 significant bits), three
+ *          v_mfma_f32_32x32x16_f16 per product block; activations must stay within +-65504. */
+#define DAD_PREC_FP32 0
+#define DAD_PREC_F16X3 1
+
 typedef struct dad_model dad_model;
 typedef void* dad_stream_t; /* hipStream_t */
 
@@ -75,6 +83,11 @@ int dad_model_load_weight(dad_model* m, const char* key, const float* data,
  * posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped. */
 int dad_model_load_schedule(dad_model* m, const float* sqrt_recip, const float* sqrt_recipm1,
                             const float* coef1, const float* coef2, const float* log_var);
+
+/* No reference counterpart (the reference computes in whatever dtype the module holds, fp32 in
+ * scripts/evaluate.py): selects the conv arithmetic, DAD_PREC_*.  Takes effect at the next
+ * dad_model_finalize (weights are re-packed); a finalized model must be finalized again. */
+int dad_model_set_precision(dad_model* m, int32_t precision);
 
 /* Checks every tensor is present, builds the per-timestep time-embedding tables
  * (SinusoidalPosEmb + time_mlp + every block's Mish->Linear, temporal_unet.py:19-32,
