@@ -430,6 +430,72 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         }
     };
 
+    // ---- rolling staging (split-f16 kernels) -------------------------------------------------
+    // Their K loop is ~3x shorter than the fp32 one, so a burst of loads behind the chunk barrier
+    // no longer hides under one chunk of MFMAs.  Instead every staged item (one float4 of W or X
+    // per thread) rolls on its own: in unit k % UW of chunk ch the item loaded during chunk ch-1
+    // (data of chunk ch+1) is written to the other LDS stage and its registers immediately receive
+    // the load for chunk ch+2.  Loads and LDS writes are spread evenly over the chunk, each load
+    // has a whole chunk period to land, and NLD loads per thread are always in flight.
+    constexpr int NLD = W_PER_T + X_PER_T;
+    auto item_store = [&](int k, int stage) {
+        const int base = stage * STAGE;
+        if (k < W_PER_T) {
+            if (W_F4 % NT == 0 || tid + k * NT < W_F4)
+                *reinterpret_cast<float4*>(&smem[base + w_loff[k]]) = wreg[k];
+        } else {
+            const int i = k - W_PER_T;
+            if (x_loff[i] >= 0) {
+                float2 hi, lo;
+                float4 v = xreg[i];
+                if (!RAGGED && x_grow[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                split_f16x4(v, hi, lo);
+                *reinterpret_cast<float2*>(&smem[base + x_loff[i]]) = hi;
+                *reinterpret_cast<float2*>(&smem[base + x_loff[i] + 8]) = lo;
+            }
+        }
+    };
+    auto item_load = [&](int k, int chunk) {
+        if (k < W_PER_T) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (W_F4 % NT == 0 || tid + k * NT < W_F4)
+                v = *reinterpret_cast<const float4*>(p.w + chunk * w_chunk_stride + w_goff[k]);
+            wreg[k] = v;
+        } else {
+            const int i = k - W_PER_T;
+            const int c0 = chunk * KC;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (!RAGGED) {
+                const bool second = c0 >= p.cin0;
+                const float* xsrc = second ? p.src1 : p.src0;
+                const int cs = second ? p.cin1 : p.cin0;
+                const int cb = second ? c0 - p.cin0 : c0;
+                // unconditional (rows that do not exist read row 0 and are zeroed at the store):
+                // a load under a lane predicate makes hipcc wait vmcnt(0) at its use, which would
+                // drain the younger loads of the rolling window
+                v = *reinterpret_cast<const float4*>(xsrc + (long)max(x_grow[i], 0) * cs + cb + x_q4[i]);
+            } else {
+                const int cc = c0 + x_q4[i];
+                if (x_grow[i] >= 0 && cc < cin) {
+                    const bool second = cc >= p.cin0;
+                    const int cs = second ? p.cin1 : p.cin0;
+                    const int cl = second ? cc - p.cin0 : cc;
+                    const float* g = (second ? p.src1 : p.src0) + (long)x_grow[i] * cs + cl;
+                    const int left = cs - cl;
+                    if ((cs & 3) == 0) {
+                        v = *reinterpret_cast<const float4*>(g);
+                    } else {
+                        if (left > 0) v.x = g[0];
+                        if (left > 1) v.y = g[1];
+                        if (left > 2) v.z = g[2];
+                        if (left > 3) v.w = g[3];
+                    }
+                }
+            }
+            xreg[i] = v;
+        }
+    };
+
     // ---- main loop -------------------------------------------------------------------------
     // Software pipeline (explicit, the compiler does not build it):
     //   * global -> register prefetch runs TWO chunks ahead: the loads of chunk c+2 are issued
@@ -607,34 +673,71 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     float4 ah = frag_a(0, 0), al = frag_a_lo(0, 0), bh = frag_b(0, 0), bl = frag_b_lo(0, 0);
     DAD_STAMP(1);
     DAD_CLOCK(6);
-    for (int ch = c_begin; ch < nchunks; ++ch) {
-        const int cur = (ch - c_begin) & 1;
-#pragma unroll
-        for (int u = 0; u < UW; ++u) {
-            float4 nah = ah, nal = al, nbh = bh, nbl = bl;
-            if (u + 1 < UW) {
-                nah = frag_a(cur, u + 1); nbh = frag_b(cur, u + 1);
-                nal = frag_a_lo(cur, u + 1); nbl = frag_b_lo(cur, u + 1);
-            } else {
-                if (ch + 1 < nchunks) store_stage(cur ^ 1);
-                __syncthreads();
-                if (ch + 2 < nchunks) load_stage(ch + 2);
-                if (ch + 1 < nchunks) {
-                    nah = frag_a(cur ^ 1, 0); nbh = frag_b(cur ^ 1, 0);
-                    nal = frag_a_lo(cur ^ 1, 0); nbl = frag_b_lo(cur ^ 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),
-                                                         __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),
-                                                          __builtin_bit_cast(f16x8, bl), acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al),
-                                                          __builtin_bit_cast(f16x8, bh), acc3, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            ah = nah; al = nal; bh = nbh; bl = nbl;
-        }
+    // Item k rolls in unit (k * UW) / NLD: the issue order inside a chunk equals the natural order
+    // 0..NLD-1 of the prologue, so "NLD-1 younger loads" holds on every path into the loop and the
+    // compiler's s_waitcnt is exact (vmcnt(NLD-1)).  The steady-state body is branch-free for the
+    // same reason: a load under a condition makes hipcc fall back to vmcnt(0), which would expose
+    // a full L2 round trip per unit.  The last two chunks run as peeled variants.
+#ifndef DAD_ABLATE_STAGE
+#define DAD_X3_ROLL(STORE, LOAD)                                                                 \
+    _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                                            \
+        if ((k * UW) / NLD != u) continue;                                                       \
+        if (STORE) item_store(k, cur ^ 1);                                                       \
+        if (LOAD) item_load(k, ch + 2);                                                          \
     }
+#else
+#define DAD_X3_ROLL(STORE, LOAD)
+#endif
+#ifndef DAD_ABLATE_BARRIER
+#define DAD_X3_SYNC() __syncthreads();
+#else
+#define DAD_X3_SYNC()
+#endif
+#ifndef DAD_ABLATE_LDSREAD
+#define DAD_X3_READ(ST, U)                                                                       \
+    nah = frag_a(ST, U); nbh = frag_b(ST, U); nal = frag_a_lo(ST, U); nbl = frag_b_lo(ST, U);
+#else
+#define DAD_X3_READ(ST, U)
+#endif
+#ifndef DAD_ABLATE_MFMA
+#define DAD_X3_MFMA()                                                                            \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),                  \
+                                                 __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);   \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),                 \
+                                                  __builtin_bit_cast(f16x8, bl), acc2, 0, 0, 0); \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al),                 \
+                                                  __builtin_bit_cast(f16x8, bh), acc3, 0, 0, 0);
+#else
+#define DAD_X3_MFMA() acc[0] += ah.x * bh.x + al.y * bl.y;
+#endif
+    // STORE: chunk ch+1 exists (its operands go to the other stage); LOAD: chunk ch+2 exists
+#define DAD_X3_CHUNK(STORE, LOAD)                                                                \
+    {                                                                                            \
+        const int cur = (ch - c_begin) & 1;                                                      \
+        _Pragma("unroll") for (int u = 0; u < UW; ++u) {                                         \
+            float4 nah = ah, nal = al, nbh = bh, nbl = bl;                                       \
+            DAD_X3_ROLL(STORE, LOAD)                                                             \
+            if (u + 1 < UW) {                                                                    \
+                DAD_X3_READ(cur, u + 1)                                                          \
+            } else {                                                                             \
+                DAD_X3_SYNC()                                                                    \
+                if (STORE) { DAD_X3_READ(cur ^ 1, 0) }                                           \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DAD_X3_MFMA()                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            ah = nah; al = nal; bh = nbh; bl = nbl;                                              \
+        }                                                                                        \
+    }
+    int ch = c_begin;
+    for (; ch + 2 < nchunks; ++ch) DAD_X3_CHUNK(true, true)
+    if (ch + 1 < nchunks) { DAD_X3_CHUNK(true, false) ++ch; }
+    if (ch < nchunks) DAD_X3_CHUNK(false, false)
+#undef DAD_X3_CHUNK
+#undef DAD_X3_ROLL
+#undef DAD_X3_SYNC
+#undef DAD_X3_READ
+#undef DAD_X3_MFMA
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc[r] * p.c1 + (acc2[r] + acc3[r]) * p.c2;
     }
