@@ -31,16 +31,6 @@
 
 namespace dad {
 
-// -DDAD_W_DMA=1 stages the weight slabs global -> LDS directly (LDS-DMA, global_load_lds_dwordx4,
-// XOR-swizzled lane-linear image) instead of through registers.  Measured on MI355X at the bench
-// workload: 99.0 ms per loop against 88.2 ms for register staging (five 1-KiB DMA pieces per wave
-// and chunk cost more issue time beside the MFMAs than five global_load_dwordx4 + ds_write_b128),
-// so the default is register staging; the variant is kept for A/B on other shapes.
-#ifndef DAD_W_DMA
-#define DAD_W_DMA 0
-#endif
-constexpr bool kWDma = DAD_W_DMA != 0;
-
 #define DAD_LBID (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
 #ifdef DAD_STAMPS
 #define DAD_STAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && DAD_LBID < 4096) p.stamps[DAD_LBID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -175,12 +165,6 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS at (wave-uniform base + lane*16).
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
 // Rows of the X stage: every sample of the tile with its zero halo.
 __host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
     return (BN / Lout) * (Lin + 2 * (taps / 2));
@@ -190,7 +174,7 @@ __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int ta
                                                   int Lout, int SK) {
     const size_t kp = KC + 4;
     const size_t stage = (size_t)conv_xrows(BN, Lin, Lout, taps) * kp +
-                         (size_t)taps * BM * (kWDma ? (size_t)KC : kp);
+                         (size_t)taps * BM * kp;
     const size_t epi = (size_t)SK * BN * (BM + 4) + 64;
     const size_t k = 2 * stage;
     return k > epi ? k : epi;
@@ -213,7 +197,6 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     constexpr int KG = KC < 16 ? KC : 16;        // packing granule of the weights
     constexpr int NSUB = KC / KG;                // packed granules per chunk
     static_assert(KC % KU == 0 && G % SK == 0 && GW >= 1, "K chunk must split evenly over the SK waves");
-    static_assert(!X3 || !kWDma, "split-f16 operands use register staging");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef DAD_ABLATE_NULL
@@ -250,8 +233,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int nvalid = min(SPT, p.B - s0);
 
     const int XF = XROWS * KP;
-    constexpr int WP = kWDma ? KC : KP;          // W row stride: DMA images are lane-linear (unpadded)
-    const int STAGE = XF + TAPS * BM * WP;       // floats per stage: [X rows][W rows]
+    const int STAGE = XF + TAPS * BM * KP;       // floats per stage: [X rows][W rows]
 
 
     // A operand (activations): lane's GEMM row n -> LDS row of tap 0
@@ -261,15 +243,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int phase_shift = (TAPS == 2 && p.interleave && m0 >= (p.M >> 1)) ? 1 : 0;
     const int arow = ((n_loc >> p.lshift) * SEG + (n_loc & (Lout - 1)) * STRIDE + phase_shift) * KP + 4 * h;
     // B operand (weights): lane's output channel
-    // LDS-DMA writes 64 lanes x 16 B linearly, so W rows cannot be padded; bank conflicts of the
-    // ds_read_b128 are removed by XOR-swizzling the 16-B slot inside a row with the row index
-    // (applied on the DMA's per-lane SOURCE address and on the read; guide rule 21).
-    constexpr int SPR = KC / 4;                              // 16-B slots per W row
-    constexpr int SWZ_SHIFT = SPR >= 16 ? 0 : (SPR == 8 ? 1 : SPR == 4 ? 2 : 3);
-    constexpr int SWZ_MASK = SPR >= 16 ? 15 : SPR - 1;
-    const int brow = kWDma ? XF + (tm * 32 + l32) * WP
-                           : XF + (tm * 32 + l32) * KP + 4 * h;
-    const int bswz = ((tm * 32 + l32) >> SWZ_SHIFT) & SWZ_MASK;   // (tap*BM adds 0 mod the mask)
+    const int brow = XF + (tm * 32 + l32) * KP + 4 * h;
 
     // four independent accumulation chains per wave (one per k-step of a unit), summed pairwise in
     // the epilogue: 4x shorter fp32 chains than a single accumulator (K reaches 20480 on the wide
@@ -327,116 +301,20 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     }
     DAD_PSTAMP(6);
     const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
-    // LDS-DMA descriptors of this wave: instruction q moves the 1 KiB [q*256, q*256+256) floats of
-    // the W image; lane -> (row, physical slot) -> swizzled logical slot -> packed global address.
-    constexpr int NWAVES = WT * SK;
-    constexpr int W_INSTR = TAPS * BM * KC / 256;
-    constexpr int D_PER_W = (W_INSTR + NWAVES - 1) / NWAVES;
-    int d_goff[D_PER_W];
-    if (kWDma) {
-#pragma unroll
-        for (int i = 0; i < D_PER_W; ++i) {
-            const int q = wave + i * NWAVES;
-            const int fl = q * 256 + lane * 4;                  // float index inside the W image
-            const int row = fl / KC;                            // tap*BM + m
-            const int ps = (fl - row * KC) >> 2;                // physical 16-B slot in the row
-            const int sl = ps ^ ((row >> SWZ_SHIFT) & SWZ_MASK);// logical slot stored there
-            const int tap = row / BM;
-            const int mm = row - tap * BM;
-            const int sub = sl / GQ;
-            d_goff[i] = ((sub * TAPS + tap) * M + m0 + mm) * KG + (sl - sub * GQ) * 4;
-        }
-    }
     // RAGGED = false promises (host-checked) that every K chunk lies inside one concat source and
     // below cin, with 16-byte aligned channel quads: the X loads use one base pointer per chunk.
     // RAGGED = true is the general path: first layer (cin = transition_dim), narrow nets.
-
-    auto load_stage = [&](int chunk) {
-        const float* wsrc = p.w + chunk * w_chunk_stride;
-        if constexpr (kWDma) {
-            float* wimg = smem + ((chunk - c_begin) & 1) * STAGE + XF;
-#pragma unroll
-            for (int i = 0; i < D_PER_W; ++i) {
-                const int q = wave + i * NWAVES;
-                if (W_INSTR % NWAVES == 0 || q < W_INSTR) glds16(wsrc + d_goff[i], wimg + q * 256);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < W_PER_T; ++i) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (W_F4 % NT == 0 || tid + i * NT < W_F4)
-                    v = *reinterpret_cast<const float4*>(wsrc + w_goff[i]);
-                wreg[i] = v;
-            }
-        }
-        const int c0 = chunk * KC;
-        if constexpr (!RAGGED) {
-            // whole chunk inside one source and inside cin: one pointer per chunk
-            const bool second = c0 >= p.cin0;
-            const float* xsrc = second ? p.src1 : p.src0;
-            const int cs = second ? p.cin1 : p.cin0;      // row stride of the source
-            const int cb = second ? c0 - p.cin0 : c0;
-#pragma unroll
-            for (int i = 0; i < X_PER_T; ++i) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (x_grow[i] >= 0)
-                    v = *reinterpret_cast<const float4*>(xsrc + (long)x_grow[i] * cs + cb + x_q4[i]);
-                xreg[i] = v;
-            }
-        } else {
-#pragma unroll
-        for (int i = 0; i < X_PER_T; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int cc = c0 + x_q4[i];                  // first channel of this float4
-            if (x_grow[i] >= 0 && cc < cin) {             // beyond cin: zero padding of the chunk
-                // virtual concat: channels [0, cin0) come from src0, the rest from src1
-                const bool second = cc >= p.cin0;
-                const int cs = second ? p.cin1 : p.cin0;  // row stride of that source
-                const int cl = second ? cc - p.cin0 : cc;
-                const float* g = (second ? p.src1 : p.src0) + (long)x_grow[i] * cs + cl;
-                const int left = cs - cl;                 // channels remaining in this source
-                if ((cs & 3) == 0) {
-                    v = *reinterpret_cast<const float4*>(g);
-                } else {                                  // first layer: cin = transition_dim
-                    if (left > 0) v.x = g[0];
-                    if (left > 1) v.y = g[1];
-                    if (left > 2) v.z = g[2];
-                    if (left > 3) v.w = g[3];
-                }
-            }
-            xreg[i] = v;
-        }
-        }
-    };
-    auto store_stage = [&](int stage) {
-        const int base = stage * STAGE;
-        if constexpr (!kWDma) {
-#pragma unroll
-            for (int i = 0; i < W_PER_T; ++i)
-                if (W_F4 % NT == 0 || tid + i * NT < W_F4)
-                    *reinterpret_cast<float4*>(&smem[base + w_loff[i]]) = wreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < X_PER_T; ++i) {
-            if (x_loff[i] < 0) continue;
-            if constexpr (X3) {
-                float2 hi, lo;
-                split_f16x4(xreg[i], hi, lo);
-                *reinterpret_cast<float2*>(&smem[base + x_loff[i]]) = hi;
-                *reinterpret_cast<float2*>(&smem[base + x_loff[i] + 8]) = lo;
-            } else {
-                *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = xreg[i];
-            }
-        }
-    };
-
-    // ---- rolling staging (split-f16 kernels) -------------------------------------------------
-    // Their K loop is ~3x shorter than the fp32 one, so a burst of loads behind the chunk barrier
-    // no longer hides under one chunk of MFMAs.  Instead every staged item (one float4 of W or X
-    // per thread) rolls on its own: in unit k % UW of chunk ch the item loaded during chunk ch-1
-    // (data of chunk ch+1) is written to the other LDS stage and its registers immediately receive
-    // the load for chunk ch+2.  Loads and LDS writes are spread evenly over the chunk, each load
-    // has a whole chunk period to land, and NLD loads per thread are always in flight.
+    //
+    // Rolling staging.  A staged "item" is one float4 of W or X per thread; a chunk has NLD of
+    // them.  In unit (k * UW) / NLD of chunk ch, item k — loaded during chunk ch-1 with the data of
+    // chunk ch+1 — is written to the other LDS stage and its registers immediately receive the
+    // load for chunk ch+2.  Loads and LDS writes are spread evenly over the chunk instead of
+    // bunching around the barrier, each load has a whole chunk period to land, and NLD loads per
+    // thread are always in flight.  (The dealing keeps the issue order inside a chunk equal to the
+    // natural order 0..NLD-1 of the prologue, so "NLD-1 younger loads" holds on every path into
+    // the loop and hipcc's s_waitcnt comes out exact; the steady-state body is branch-free for
+    // the same reason — a load under a condition makes hipcc fall back to vmcnt(0), a full L2
+    // round trip exposed per unit.  The last two chunks run as peeled variants.)
     constexpr int NLD = W_PER_T + X_PER_T;
     auto item_store = [&](int k, int stage) {
         const int base = stage * STAGE;
@@ -446,12 +324,16 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         } else {
             const int i = k - W_PER_T;
             if (x_loff[i] >= 0) {
-                float2 hi, lo;
                 float4 v = xreg[i];
-                if (!RAGGED && x_grow[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                split_f16x4(v, hi, lo);
-                *reinterpret_cast<float2*>(&smem[base + x_loff[i]]) = hi;
-                *reinterpret_cast<float2*>(&smem[base + x_loff[i] + 8]) = lo;
+                if (!RAGGED && x_grow[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);   // no such sample
+                if constexpr (X3) {
+                    float2 hi, lo;
+                    split_f16x4(v, hi, lo);
+                    *reinterpret_cast<float2*>(&smem[base + x_loff[i]]) = hi;
+                    *reinterpret_cast<float2*>(&smem[base + x_loff[i] + 8]) = lo;
+                } else {
+                    *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = v;
+                }
             }
         }
     };
@@ -466,25 +348,25 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             const int c0 = chunk * KC;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (!RAGGED) {
+                // whole chunk inside one source and inside cin: one pointer per chunk.  The load is
+                // unconditional (rows that do not exist read row 0 and are zeroed at the store)
                 const bool second = c0 >= p.cin0;
                 const float* xsrc = second ? p.src1 : p.src0;
-                const int cs = second ? p.cin1 : p.cin0;
+                const int cs = second ? p.cin1 : p.cin0;      // row stride of the source
                 const int cb = second ? c0 - p.cin0 : c0;
-                // unconditional (rows that do not exist read row 0 and are zeroed at the store):
-                // a load under a lane predicate makes hipcc wait vmcnt(0) at its use, which would
-                // drain the younger loads of the rolling window
                 v = *reinterpret_cast<const float4*>(xsrc + (long)max(x_grow[i], 0) * cs + cb + x_q4[i]);
             } else {
-                const int cc = c0 + x_q4[i];
-                if (x_grow[i] >= 0 && cc < cin) {
+                const int cc = c0 + x_q4[i];                  // first channel of this float4
+                if (x_grow[i] >= 0 && cc < cin) {             // beyond cin: zero padding of the chunk
+                    // virtual concat: channels [0, cin0) come from src0, the rest from src1
                     const bool second = cc >= p.cin0;
-                    const int cs = second ? p.cin1 : p.cin0;
+                    const int cs = second ? p.cin1 : p.cin0;  // row stride of that source
                     const int cl = second ? cc - p.cin0 : cc;
                     const float* g = (second ? p.src1 : p.src0) + (long)x_grow[i] * cs + cl;
-                    const int left = cs - cl;
+                    const int left = cs - cl;                 // channels remaining in this source
                     if ((cs & 3) == 0) {
                         v = *reinterpret_cast<const float4*>(g);
-                    } else {
+                    } else {                                  // first layer: cin = transition_dim
                         if (left > 0) v.x = g[0];
                         if (left > 1) v.y = g[1];
                         if (left > 2) v.z = g[2];
@@ -496,41 +378,21 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         }
     };
 
-    // ---- main loop -------------------------------------------------------------------------
-    // Software pipeline (explicit, the compiler does not build it):
-    //   * global -> register prefetch runs TWO chunks ahead: the loads of chunk c+2 are issued
-    //     right after the registers of chunk c+1 were drained into LDS, and are not needed
-    //     until a whole chunk of MFMAs later;
-    //   * MFMA operand fragments are read one unit (4 MFMAs) ahead, so every ds_read_b128 has
-    //     >= 256 matrix-pipe cycles to land;
-    //   * the chunk's single barrier sits in FRONT of its last unit's MFMAs: the first
-    //     fragments of the next chunk are fetched behind the barrier while those MFMAs run, so
-    //     the matrix pipe does not drain at the barrier.
-    constexpr int UW = TAPS * GW;                       // units (4 MFMAs each) per wave per chunk
+    // ---- MFMA operand fragments ---------------------------------------------------------------
+    // Fragments are read one unit ahead of the MFMAs that consume them; the chunk's single barrier
+    // sits in FRONT of its last unit's MFMAs: the first fragments of the next chunk are fetched
+    // behind the barrier while those MFMAs run, so the matrix pipe does not drain at the barrier.
+    constexpr int UW = TAPS * GW;                       // units per wave per chunk
     const int koff = ks * (GW * KU);                    // this wave's units in a chunk
     const int afrag = arow + koff;
     const int bfrag = brow + koff;
-    auto frag_a = [&](int stage, int u) -> float4 {
+    auto frag_a = [&](int stage, int u, int lo) -> float4 {   // lo = 8: the residual halves (X3)
         const int tap = u / GW, gw = u - tap * GW;
-        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * KU]);
+        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * KU + lo]);
     };
-    auto frag_a_lo = [&](int stage, int u) -> float4 {      // split-f16: the residual halves
+    auto frag_b = [&](int stage, int u, int lo) -> float4 {
         const int tap = u / GW, gw = u - tap * GW;
-        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * KU + 8]);
-    };
-    int bsl[GW];                                        // swizzled slot offsets (floats), per group
-#pragma unroll
-    for (int gw = 0; gw < GW; ++gw) bsl[gw] = (((ks * GW + gw) * 2 + h) ^ bswz) * 4;
-    auto frag_b = [&](int stage, int u) -> float4 {
-        const int tap = u / GW, gw = u - tap * GW;
-        if constexpr (kWDma)
-            return *reinterpret_cast<const float4*>(&smem[stage * STAGE + brow + tap * BM * WP + bsl[gw]]);
-        else
-            return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * KU]);
-    };
-    auto frag_b_lo = [&](int stage, int u) -> float4 {
-        const int tap = u / GW, gw = u - tap * GW;
-        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * KU + 8]);
+        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * KU + lo]);
     };
 
     // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
@@ -597,7 +459,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         if (p.res != nullptr && !p.interleave && eoff[k] >= 0) res4[k] = ldg4(p.res + eoff[k]);  \
     }
     DAD_PSTAMP(7);
-    load_stage(c_begin);                   // first global loads fly while LDS is being zeroed
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) item_load(k, c_begin);   // first global loads fly while LDS is zeroed
     if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }   // younger than the stage loads: not waited with them
     DAD_PSTAMP(1);
     // zero both X stages once: halo rows (and rows of samples that do not exist) stay zero,
@@ -608,138 +471,99 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     }
     __syncthreads();                       // zero fill done before real rows land
     DAD_PSTAMP(2);
-    store_stage(0);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) item_store(k, 0);
     DAD_PSTAMP(3);
-    if (c_begin + 1 < nchunks) load_stage(c_begin + 1);
+    if (c_begin + 1 < nchunks) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) item_load(k, c_begin + 1);
+    }
     DAD_PSTAMP(4);
-    if constexpr (kWDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first W images landed
     __syncthreads();
     DAD_PSTAMP(5);
-    if constexpr (!X3) {
-    float4 ca = frag_a(0, 0), cb = frag_b(0, 0);
-    DAD_STAMP(1);
-    DAD_CLOCK(6);
 
-    for (int ch = c_begin; ch < nchunks; ++ch) {
-        const int cur = (ch - c_begin) & 1;
-#pragma unroll
-        for (int u = 0; u < UW; ++u) {
-            float4 na = ca, nb = cb;
-            // (DAD_ABLATE_* exist only in timing-only diagnostic builds: wrong results by design)
-            if (u + 1 < UW) {
-#ifndef DAD_ABLATE_LDSREAD
-                na = frag_a(cur, u + 1);
-                nb = frag_b(cur, u + 1);
-#endif
-            } else {
-#ifndef DAD_ABLATE_STAGE
-                if (ch + 1 < nchunks) store_stage(cur ^ 1);
-#endif
-                if constexpr (kWDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // DMA landed
-#ifndef DAD_ABLATE_BARRIER
-                __syncthreads();
-#endif
-#ifndef DAD_ABLATE_STAGE
-                if (ch + 2 < nchunks) load_stage(ch + 2);
-#endif
-#ifndef DAD_ABLATE_LDSREAD
-                if (ch + 1 < nchunks) {
-                    na = frag_a(cur ^ 1, 0);
-                    nb = frag_b(cur ^ 1, 0);
-                }
-#endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef DAD_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc3, 0, 0, 0);
-            acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc4, 0, 0, 0);
-#ifdef DAD_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            ca = na;
-            cb = nb;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
-    } else {
-    // split-f16 operands: a unit is 16 channels = 3 MFMAs (hi*hi into acc, the two cross terms
-    // into acc2 / acc3, which carry a factor 2^11); same pipeline shape as above.
-    float4 ah = frag_a(0, 0), al = frag_a_lo(0, 0), bh = frag_b(0, 0), bl = frag_b_lo(0, 0);
+    // ---- main loop -------------------------------------------------------------------------
+    // fp32: a unit is 8 channels = 4 v_mfma_f32_32x32x2_f32 into four accumulation chains.
+    // split-f16: a unit is 16 channels = 3 v_mfma_f32_32x32x16_f16 (hi*hi into acc, the two cross
+    // terms into acc2 / acc3, which carry a factor 2^11).
+    // (DAD_ABLATE_* exist only in timing-only diagnostic builds: wrong results by design.)
+    float4 ah = frag_a(0, 0, 0), bh = frag_b(0, 0, 0);
+    float4 al = ah, bl = bh;
+    if constexpr (X3) { al = frag_a(0, 0, 8); bl = frag_b(0, 0, 8); }
     DAD_STAMP(1);
     DAD_CLOCK(6);
-    // Item k rolls in unit (k * UW) / NLD: the issue order inside a chunk equals the natural order
-    // 0..NLD-1 of the prologue, so "NLD-1 younger loads" holds on every path into the loop and the
-    // compiler's s_waitcnt is exact (vmcnt(NLD-1)).  The steady-state body is branch-free for the
-    // same reason: a load under a condition makes hipcc fall back to vmcnt(0), which would expose
-    // a full L2 round trip per unit.  The last two chunks run as peeled variants.
 #ifndef DAD_ABLATE_STAGE
-#define DAD_X3_ROLL(STORE, LOAD)                                                                 \
+#define DAD_ROLL(STORE, LOAD)                                                                    \
     _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                                            \
         if ((k * UW) / NLD != u) continue;                                                       \
         if (STORE) item_store(k, cur ^ 1);                                                       \
         if (LOAD) item_load(k, ch + 2);                                                          \
     }
 #else
-#define DAD_X3_ROLL(STORE, LOAD)
+#define DAD_ROLL(STORE, LOAD)
 #endif
 #ifndef DAD_ABLATE_BARRIER
-#define DAD_X3_SYNC() __syncthreads();
+#define DAD_SYNC() __syncthreads();
 #else
-#define DAD_X3_SYNC()
+#define DAD_SYNC()
 #endif
 #ifndef DAD_ABLATE_LDSREAD
-#define DAD_X3_READ(ST, U)                                                                       \
-    nah = frag_a(ST, U); nbh = frag_b(ST, U); nal = frag_a_lo(ST, U); nbl = frag_b_lo(ST, U);
+#define DAD_READ(ST, U)                                                                          \
+    nah = frag_a(ST, U, 0); nbh = frag_b(ST, U, 0);                                              \
+    if constexpr (X3) { nal = frag_a(ST, U, 8); nbl = frag_b(ST, U, 8); }
 #else
-#define DAD_X3_READ(ST, U)
+#define DAD_READ(ST, U)
 #endif
 #ifndef DAD_ABLATE_MFMA
-#define DAD_X3_MFMA()                                                                            \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),                  \
-                                                 __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);   \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),                 \
-                                                  __builtin_bit_cast(f16x8, bl), acc2, 0, 0, 0); \
-    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al),                 \
-                                                  __builtin_bit_cast(f16x8, bh), acc3, 0, 0, 0);
+#define DAD_MFMA()                                                                               \
+    if constexpr (X3) {                                                                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),              \
+                                                     __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);  \
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),             \
+                                                      __builtin_bit_cast(f16x8, bl), acc2, 0, 0, 0); \
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al),             \
+                                                      __builtin_bit_cast(f16x8, bh), acc3, 0, 0, 0); \
+    } else {                                                                                     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.x, bh.x, acc, 0, 0, 0);                    \
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.y, bh.y, acc2, 0, 0, 0);                  \
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.z, bh.z, acc3, 0, 0, 0);                  \
+        acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.w, bh.w, acc4, 0, 0, 0);                  \
+    }
 #else
-#define DAD_X3_MFMA() acc[0] += ah.x * bh.x + al.y * bl.y;
+#define DAD_MFMA() acc[0] += ah.x * bh.x + al.y * bl.y;
 #endif
     // STORE: chunk ch+1 exists (its operands go to the other stage); LOAD: chunk ch+2 exists
-#define DAD_X3_CHUNK(STORE, LOAD)                                                                \
+#define DAD_CHUNK(STORE, LOAD)                                                                   \
     {                                                                                            \
         const int cur = (ch - c_begin) & 1;                                                      \
         _Pragma("unroll") for (int u = 0; u < UW; ++u) {                                         \
             float4 nah = ah, nal = al, nbh = bh, nbl = bl;                                       \
-            DAD_X3_ROLL(STORE, LOAD)                                                             \
+            DAD_ROLL(STORE, LOAD)                                                                \
             if (u + 1 < UW) {                                                                    \
-                DAD_X3_READ(cur, u + 1)                                                          \
+                DAD_READ(cur, u + 1)                                                             \
             } else {                                                                             \
-                DAD_X3_SYNC()                                                                    \
-                if (STORE) { DAD_X3_READ(cur ^ 1, 0) }                                           \
+                DAD_SYNC()                                                                       \
+                if (STORE) { DAD_READ(cur ^ 1, 0) }                                              \
             }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
-            DAD_X3_MFMA()                                                                        \
+            DAD_MFMA()                                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                   \
             ah = nah; al = nal; bh = nbh; bl = nbl;                                              \
         }                                                                                        \
     }
     int ch = c_begin;
-    for (; ch + 2 < nchunks; ++ch) DAD_X3_CHUNK(true, true)
-    if (ch + 1 < nchunks) { DAD_X3_CHUNK(true, false) ++ch; }
-    if (ch < nchunks) DAD_X3_CHUNK(false, false)
-#undef DAD_X3_CHUNK
-#undef DAD_X3_ROLL
-#undef DAD_X3_SYNC
-#undef DAD_X3_READ
-#undef DAD_X3_MFMA
+    for (; ch + 2 < nchunks; ++ch) DAD_CHUNK(true, true)
+    if (ch + 1 < nchunks) { DAD_CHUNK(true, false) ++ch; }
+    if (ch < nchunks) DAD_CHUNK(false, false)
+#undef DAD_CHUNK
+#undef DAD_ROLL
+#undef DAD_SYNC
+#undef DAD_READ
+#undef DAD_MFMA
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acc[r] * p.c1 + (acc2[r] + acc3[r]) * p.c2;
+    for (int r = 0; r < 16; ++r) {
+        if constexpr (X3) acc[r] = acc[r] * p.c1 + (acc2[r] + acc3[r]) * p.c2;
+        else acc[r] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
     }
     __syncthreads();                       // all MFMAs retired before the stage memory is reused
     DAD_STAMP(2);
