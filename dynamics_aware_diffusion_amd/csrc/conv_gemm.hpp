@@ -463,13 +463,21 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     for (int k = 0; k < NLD; ++k) item_load(k, c_begin);   // first global loads fly while LDS is zeroed
     if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }   // younger than the stage loads: not waited with them
     DAD_PSTAMP(1);
-    // zero both X stages once: halo rows (and rows of samples that do not exist) stay zero,
-    // staging only ever writes real positions.  (XF is a multiple of 4 floats.)
-    for (int i = tid * 4; i < XF; i += NT * 4) {
-        *reinterpret_cast<float4*>(&smem[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&smem[STAGE + i]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Zero the halo rows of both X stages once (PAD rows on either side of every sample).  Real
+    // rows — including those of samples beyond the batch, which get zeros — are rewritten in full
+    // by every chunk's staging, so nothing else needs clearing and, the two sets of rows being
+    // disjoint, no barrier separates this from the first stores.
+    if constexpr (PAD > 0) {
+        constexpr int KP4 = KP / 4;
+        const int nz = SPT * (2 * PAD) * KP4;
+        for (int i = tid; i < nz; i += NT) {
+            const int hr = i / KP4, c4 = i - hr * KP4;
+            const int s = hr / (2 * PAD), j = hr - s * (2 * PAD);
+            const int row = s * SEG + (j < PAD ? j : Lin + j);
+            *reinterpret_cast<float4*>(&smem[row * KP + c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&smem[STAGE + row * KP + c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-    __syncthreads();                       // zero fill done before real rows land
     DAD_PSTAMP(2);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) item_store(k, 0);
