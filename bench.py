@@ -34,7 +34,9 @@ from dynamics_aware_diffusion_amd import GaussianDiffusion, GuidedPolicy, Tempor
 from dynamics_aware_diffusion_amd.utils import synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2516.6     # same guide: 16x the f32 MFMA rate (v_mfma_f32_32x32x16_f16), dense
 PEAK_HBM_GBS = 8000.0
+PEAK_HBM_TBS = PEAK_HBM_GBS / 1e3
 
 WORKLOADS = {
     # name: (arch key, batch per GPU, description)
@@ -94,7 +96,7 @@ def cpu_baseline(arch: str, batch: int, state, budget_s: float = 15.0):
             od_.denoise_step(w, sched, x, t, z)
             n += 1
             el = time.perf_counter() - t0
-            if el >= budget_s or n >= T:
+            if el >= budget_s or n >= 4 * T:
                 break
     step_s = el / n
     return {
@@ -115,6 +117,8 @@ def main() -> None:
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
                     help="conv arithmetic: exact fp32 MFMA, or split-f16 operands (3 f16 MFMAs per "
                          "product block, fp32 accumulation; same parity gates)")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the second pass with the other conv arithmetic")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent sampling loops kept in flight on separate HIP streams "
                          "(diagnostic: shows how much of a step is dependency bubbles; the "
@@ -198,26 +202,33 @@ def main() -> None:
     assert torch.isfinite(plans).all()
 
     # ---- instrumented pass: HIP events around every conv-GEMM launch, on the launch stream
-    roof = None
-    if rank == 0:
-        eng = diff._engine(device)
-        diff.use_graph = False                # events are recorded on eager launches
+    f = synth.unet_flops_per_sample(td, dim, mults, 32)
+    P = synth.count_params(synth.unet_param_shapes(td, dim, mults))
+    a_elems = None
+
+    def roofline_of(policy_, diff_, precision, loop_s):
+        """Rank-0-only pass (NO collective in here): one loop with HIP events bracketing each
+        denoiser evaluation's conv-GEMM launches on the launch stream."""
+        eng = diff_._engine(device)
+        graph = diff_.use_graph
+        diff_.use_graph = False               # events are recorded on eager launches
         eng.profile_enable(True)
-        diff.seed = 10_000                    # rank-0-only pass: NO collective in here
-        policy.sample_loop(batch_size=batch, conditions=cond, row_offset=rank * batch)
+        diff_.seed = 10_000
+        policy_.sample_loop(batch_size=batch, conditions=cond, row_offset=rank * batch)
         torch.cuda.synchronize()
         conv_ms, launches, conv_flops = eng.profile_read()
         eng.profile_enable(False)
+        diff_.use_graph = graph
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-        f = synth.unet_flops_per_sample(td, dim, mults, 32)
-        P = synth.count_params(synth.unet_param_shapes(td, dim, mults))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                traffic = json.load(open(tpath)).get(args.workload if precision == "fp32"
+                                                     else args.workload + ":" + precision)
             except Exception:
                 traffic = None
+        hbm_bytes = 4 * P + 12 * batch * 32 * td              # SURVEY 8(d) floor per denoise step
         roof = {
             "bound": "mfma", "kernel": "dad::conv_gemm_f32<*> (all tile variants)",
             "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -225,9 +236,56 @@ def main() -> None:
             "launches": launches, "avg_launch_us": conv_ms * 1e3 / max(launches, 1),
             "flops_per_launch": conv_flops / max(launches, 1),
             "conv_ms_per_loop": conv_ms,
-            "whole_step_tflops": f * batch * T * args.steps / elapsed / 1e12,
-            "hbm_model_bytes_per_denoise_step": 4 * P + 12 * batch * 32 * td,
+            "whole_step_tflops": f * batch * T / loop_s / 1e12,
+            "hbm_model_bytes_per_denoise_step": hbm_bytes,
+            "hbm_frac": hbm_bytes * T / loop_s / (PEAK_HBM_TBS * 1e12),
         }
+        if precision == "f16x3":
+            # the same algorithmic FLOPs run as 3 f16 MFMAs per product block: against the f16
+            # matrix peak the EXECUTED rate is 3 x achieved; the fp32-peak fraction above is kept
+            # because it is the roofline SURVEY 8(d) prices every configuration against
+            roof["executed_f16_tflops"] = 3 * achieved
+            roof["peak_f16_mfma"] = PEAK_F16_MFMA_TFLOPS
+            roof["frac_of_f16_peak_executed"] = 3 * achieved / PEAK_F16_MFMA_TFLOPS
+        return roof
+
+    roof = None
+    if rank == 0:
+        roof = roofline_of(policy, diff, args.precision, elapsed / args.steps)
+
+    # ---- the other conv arithmetic, same workload, same run (one GPU only; reported beside the
+    # headline, never as `value`)
+    alt = None
+    if rank == 0 and world == 1 and args.inflight == 1 and not args.no_alt:
+        other = "f16x3" if args.precision == "fp32" else "fp32"
+        pol2, diff2, cond2, _ = build_policy(arch, device, other)
+        diff2.use_graph = diff.use_graph
+
+        def alt_steps(first, count):
+            out_ = None
+            for k in range(count):
+                diff2.seed = 1000 + first + k
+                out_ = pol2.sample_loop(batch_size=batch, conditions=cond2, row_offset=0)
+            return out_
+
+        alt_steps(0, max(1, args.warmup))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        plans2 = alt_steps(args.warmup, args.steps)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        assert torch.isfinite(plans2).all()
+        # same seeds as the headline loop: the two arithmetics must agree to the fp32 tolerance
+        diff.seed = diff2.seed = 4242
+        pa = policy.sample_loop(batch_size=batch, conditions=cond, row_offset=0)
+        pb = pol2.sample_loop(batch_size=batch, conditions=cond2, row_offset=0)
+        alt = {
+            "conv_arithmetic": other, "value": batch * args.steps / el2, "unit": "plans/s",
+            "ms_per_step": el2 / args.steps * 1e3,
+            "max_abs_diff_vs_headline_plans": float((pa - pb).abs().max()),
+            "roofline": roofline_of(pol2, diff2, other, el2 / args.steps),
+        }
+        del pol2, diff2
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -243,8 +301,8 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "arch": arch, "batch_per_gpu": batch,
                        "global_batch": world * batch, "horizon": 32, "denoise_steps": T,
-                       "rng": "in-kernel philox", "conv_arithmetic": args.precision, "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end", "loops_in_flight": args.inflight},
-            "roofline": roof, "cpu_baseline": base,
+                       "rng": "in-kernel philox", "conv_arithmetic": args.precision + (" (exact fp32 MFMA)" if args.precision == "fp32" else " (split-f16 operands, fp32 accumulate)"), "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end", "loops_in_flight": args.inflight},
+            "roofline": roof, "cpu_baseline": base, "alt_precision": alt,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -25,7 +25,7 @@ stats = one("trace/**/*_kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
 
-summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"}
+summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt"}
 trace = one("trace/**/*_kernel_trace.csv")
 if trace:
     rows = [r for r in csv.DictReader(open(trace)) if "dad::" in r["Kernel_Name"]]
@@ -77,6 +77,35 @@ if sq:
     if tot.get("SQ_WAVE_CYCLES"):
         wc = tot["SQ_WAVE_CYCLES"]
         summary["sq_ratios"] = {k: tot[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in tot}
+# ---- the split-f16 arithmetic (bench.py --precision f16x3): its own stats table and traffic
+x3stats = one("x3_trace/**/*_kernel_stats.csv")
+if x3stats:
+    shutil.copy(x3stats, os.path.join(here, f"{tag}_kernel_stats_f16x3.csv"))
+x3trace = one("x3_trace/**/*_kernel_trace.csv")
+if x3trace:
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(x3trace)):
+        if "dad::" in r["Kernel_Name"]:
+            a = agg[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    conv = [(n, t) for k, (n, t) in agg.items() if "conv_gemm_f32" in k]
+    x3 = {"command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --precision f16x3",
+          "kernels_us": {k: {"calls": n, "total_us": t, "avg_us": t / n} for k, (n, t) in agg.items()},
+          "conv_gemm_all_variants": {"calls": sum(n for n, _ in conv), "total_us": sum(t for _, t in conv),
+                                     "avg_us": sum(t for _, t in conv) / max(1, sum(n for n, _ in conv))}}
+    f3, w3 = pmc("x3_fetch", "FETCH_SIZE"), pmc("x3_write", "WRITE_SIZE")
+    if f3 and w3:
+        per_launch = (2.0 * f3[0] / f3[1] + w3[0] / w3[1]) * 1024.0
+        x3["hbm_traffic"] = {"FETCH_SIZE_KiB_per_launch_raw": f3[0] / f3[1],
+                             "WRITE_SIZE_KiB_per_launch": w3[0] / w3[1],
+                             "bytes_per_conv_launch": per_launch}
+        tpath = os.path.join(here, "traffic.json")
+        cur = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        cur["pointmaze_b256:f16x3"] = per_launch
+        json.dump(cur, open(tpath, "w"), indent=1)
+    summary["f16x3"] = x3
+
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj) and os.path.getsize(bj):
     summary["bench_line"] = json.loads(open(bj).read().strip().splitlines()[-1])
