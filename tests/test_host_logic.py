@@ -58,6 +58,10 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.dad_model_load_weight(h, b"final_conv.1.bias", buf, shape, 1) == -3   # 6 expected
     # step before finalize
     assert lib.dad_unet_forward(h, None, 0, None, 1, None, 0, None) == -2
+    # conv arithmetic: the two known modes, anything else refused
+    assert lib.dad_model_set_precision(h, 1) == 0 and lib.dad_model_set_precision(h, 0) == 0
+    assert lib.dad_model_set_precision(h, 7) == -1 and b"precision" in lib.dad_last_error()
+    assert lib.dad_model_set_precision(None, 0) == -1
     lib.dad_model_destroy(h)
     # unsupported architectures are refused with a message, not a crash
     cfg.kernel_size = 3
@@ -67,6 +71,14 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     cfg.horizon = 32
     cfg.channels[1] = 48                                # not a multiple of 32
     assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_precision_names_are_validated_before_any_device_call():
+    from dynamics_aware_diffusion_amd import _engine
+    assert _engine.PRECISIONS == {"fp32": 0, "f16x3": 1}
+    with pytest.raises(ValueError, match="precision"):
+        _engine.HipEngine(transition_dim=6, dim=32, channels=(32, 64), horizon=32, n_timesteps=10,
+                          precision="bf16")
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
