@@ -43,6 +43,13 @@ WORKLOADS = {
     "pointmaze_b256": ("pointmaze", 256,
                        "PointMaze umaze-v2 guided policy, H=32 dim=128 mults(1,2,4) T=100 batch=256/GPU"),
     "pointmaze_b1": ("pointmaze", 1, "PointMaze guided policy, batch=1 (reference plumbing case)"),
+    # BASELINE config 3: T=500 and the dynamics projection after every step (opt-in in the build,
+    # the shipped reference loop never projects); "..._noproj" is the as-shipped variant
+    "pointmaze_proj_t500_b256": ("pointmaze", 256,
+                                 "PointMaze dynamics-aware policy, T=500, projection after every step "
+                                 "(noise_schedule, strength 1), batch=256/GPU"),
+    "pointmaze_noproj_t500_b256": ("pointmaze", 256,
+                                   "PointMaze dynamics-aware policy as shipped (no projection), T=500, batch=256/GPU"),
     "halfcheetah_b128": ("halfcheetah", 128,
                          "HalfCheetah medium-v2, H=32 dim=256 mults(1,4,8) T=1000 batch=128/GPU"),
     "door_b128": ("door", 128,
@@ -50,8 +57,26 @@ WORKLOADS = {
 }
 
 
-def build_policy(arch: str, device: torch.device, precision: str = "fp32"):
+class _BenchNormalizer:
+    """Synthetic normaliser statistics (SURVEY 8(d) cfg 3: mean ~ N(0,1), std ~ U(0.5,1.5))."""
+
+    def __init__(self, od: int, ad: int):
+        self.obs_mean = synth.normal_like(41, "bench.norm.obs_mean", (od,))
+        self.obs_std = 1.0 + synth.uniform(41, "bench.norm.obs_std", (od,), 0.5)
+        self.action_mean = synth.normal_like(41, "bench.norm.act_mean", (ad,))
+        self.action_std = 1.0 + synth.uniform(41, "bench.norm.act_std", (ad,), 0.5)
+
+    def normalize_observations(self, obs):
+        return (obs - self.obs_mean) / self.obs_std
+
+    def unnormalize_actions(self, a):
+        return a * self.action_std + self.action_mean
+
+
+def build_policy(arch: str, device: torch.device, precision: str = "fp32", workload: str = ""):
     od, ad, dim, mults, T = synth.ARCHS[arch]
+    if "_t500_" in workload:
+        T = 500
     td = od + ad
     unet = TemporalUnet(td, dim=dim, dim_mults=mults)
     unet.precision = precision
@@ -59,7 +84,20 @@ def build_policy(arch: str, device: torch.device, precision: str = "fp32"):
     unet.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     diff = GaussianDiffusion(unet, 32, od, ad, n_timesteps=T).to(device)
     diff.sampler_rng = "philox"
-    policy = GuidedPolicy(diff, normalizer=None)
+    if "proj_t500" in workload:               # config 3: double integrator dt=0.1, n=4, m=2, D=196
+        from dynamics_aware_diffusion_amd import DynamicsAwarePolicy
+        from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder
+        import numpy as np
+        dt = 0.1
+        A = np.eye(4); A[0, 2] = A[1, 3] = dt
+        Bm = np.zeros((4, 2)); Bm[0, 0] = Bm[1, 1] = 0.5 * dt * dt; Bm[2, 0] = Bm[3, 1] = dt
+        Pm = ProjectionMatrixBuilder(A, Bm, 4, 2).get_projection_matrix(32)
+        policy = DynamicsAwarePolicy(diff, projection_matrix=Pm, normalizer=_BenchNormalizer(od, ad),
+                                     state_dim=4, observation_dim=od, action_dim=ad, horizon=32,
+                                     projection_schedule="noise_schedule", projection_strength=1.0,
+                                     project_during_sampling=not workload.startswith("pointmaze_noproj"))
+    else:
+        policy = GuidedPolicy(diff, normalizer=None)
     cond = torch.zeros(1, td)
     cond[0, :od] = torch.from_numpy(synth.uniform(1, "bench.cond", (od,), 0.9))
     return policy, diff, {0: cond.to(device)}, state
@@ -77,10 +115,11 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(arch: str, batch: int, state, budget_s: float = 15.0):
+def cpu_baseline(arch: str, batch: int, state, budget_s: float = 15.0, n_timesteps: int = 0):
     """Time the oracle's denoise step on the host cores (bounded sample, extrapolated x T)."""
     from oracle import denoiser as od_
     od, ad, dim, mults, T = synth.ARCHS[arch]
+    T = n_timesteps or T
     td = od + ad
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -151,8 +190,10 @@ def main() -> None:
 
     arch, batch, desc = WORKLOADS[args.workload]
     od, ad, dim, mults, T = synth.ARCHS[arch]
+    if "_t500_" in args.workload:
+        T = 500
     td = od + ad
-    policy, diff, cond, state = build_policy(arch, device, args.precision)
+    policy, diff, cond, state = build_policy(arch, device, args.precision, args.workload)
     diff.use_graph = batch <= 32          # small batches are launch-bound: replay one hipGraph
     gathered = torch.empty(world * batch, 32, td, device=device) if world > 1 else None
 
@@ -174,7 +215,7 @@ def main() -> None:
 
     extra = []
     if args.inflight > 1:                     # one policy/engine + stream per loop in flight
-        extra = [(build_policy(arch, device, args.precision), torch.cuda.Stream(device)) for _ in range(args.inflight - 1)]
+        extra = [(build_policy(arch, device, args.precision, args.workload), torch.cuda.Stream(device)) for _ in range(args.inflight - 1)]
 
     def run_steps(first: int, count: int):
         out = None
@@ -258,7 +299,7 @@ def main() -> None:
     alt = None
     if rank == 0 and world == 1 and args.inflight == 1 and not args.no_alt:
         other = "f16x3" if args.precision == "fp32" else "fp32"
-        pol2, diff2, cond2, _ = build_policy(arch, device, other)
+        pol2, diff2, cond2, _ = build_policy(arch, device, other, args.workload)
         diff2.use_graph = diff.use_graph
 
         def alt_steps(first, count):
@@ -289,7 +330,7 @@ def main() -> None:
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(arch, batch, state, args.cpu_seconds)
+        base = cpu_baseline(arch, batch, state, args.cpu_seconds, T)
 
     if rank == 0:
         total_plans = world * batch * args.steps

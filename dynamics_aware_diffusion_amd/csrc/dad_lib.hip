@@ -537,7 +537,9 @@ int configure_kernels() {
     HIP_TRY(raise_lds_limit_cfg<7>());
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4>,
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
     return DAD_OK;
@@ -777,10 +779,15 @@ int run_project(const dad_project_args* pa, float alpha, float* x, int batch, in
     p.D = (horizon + 1) * p.n + horizon * p.m;
     p.alpha = alpha;
     p.one_minus_alpha = (float)(1.0 - (double)alpha);
-    constexpr int RB = 4;
-    const size_t lds = (size_t)RB * p.D * sizeof(float);
+    // rows per block: one while the batch fits one wave of blocks (every CU streams P once),
+    // four beyond that (P is then re-used by four rows per pass)
+    const int rb = batch <= 512 ? 1 : 4;
+    const size_t lds = (size_t)(1 + 16) * rb * p.D * sizeof(float);   // rows + 16 partial sets
     if (lds > 160 * 1024) return fail(DAD_E_INVALID, "projection dimension D=%d too large", p.D);
-    hipLaunchKernelGGL(dad::project_kernel<RB>, dim3((batch + RB - 1) / RB), dim3(256), lds, st, p);
+    if (rb == 1)
+        hipLaunchKernelGGL((dad::project_kernel<1, 16>), dim3(batch), dim3(1024), lds, st, p);
+    else
+        hipLaunchKernelGGL((dad::project_kernel<4, 16>), dim3((batch + 3) / 4), dim3(1024), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;
 }

@@ -77,32 +77,34 @@ struct FinalParams {
                                           // (graph replays take a fresh seed without re-capture)
 };
 
-constexpr int FINAL_COLS = 64;   // trajectory positions per block
+constexpr int FINAL_COLS = 32;   // trajectory positions per block (256 blocks at B*H = 8192)
 __host__ __device__ inline size_t final_lds_floats(int td, int dim) {
-    return (size_t)td * dim + td + (size_t)FINAL_COLS * (dim + 1);
+    return (size_t)td * dim + ((td + 3) & ~3) + (size_t)FINAL_COLS * (dim + 4);
 }
 
-// One block = 64 (b, l) positions.  The [64][dim] activation slab and the [td][dim] weights
-// are staged in LDS with coalesced loads; thread (col, jg) then produces outputs
-// j = jg, jg+4, ... of its position and applies the posterior update to them.
+// One block = 32 (b, l) positions.  The [32][dim] activation slab and the [td][dim] weights
+// are staged in LDS with coalesced float4 loads (rows padded to dim+4 floats: 16-byte aligned and
+// an odd number of 16-byte slots, conflict-free ds_read_b128); thread (col, jg) then produces
+// outputs j = jg, jg+8, ... of its position and applies the posterior update to them.
 __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams p) {
     extern __shared__ __attribute__((aligned(16))) float ws[];
     const int td = p.td, dim = p.dim;
+    const int rs = dim + 4;                // tile row stride
     float* wl = ws;                        // [td][dim]
-    float* bl = wl + td * dim;             // [td]
-    float* tile = bl + td;                 // [64][dim+1]
+    float* bl = wl + td * dim;             // [td] (+ pad to 4)
+    float* tile = bl + ((td + 3) & ~3);    // [32][dim+4]
     const long N = (long)p.B * p.H;
     const long n0 = (long)blockIdx.x * FINAL_COLS;
-    for (int i = threadIdx.x; i < td * dim; i += blockDim.x) wl[i] = p.w[i];
-    for (int i = threadIdx.x; i < td; i += blockDim.x) bl[i] = p.bias[i];
     const int dq = dim >> 2;
     for (int e = threadIdx.x; e < FINAL_COLS * dq; e += blockDim.x) {
         const int row = e / dq, q = e - row * dq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n0 + row < N) v = *reinterpret_cast<const float4*>(p.act + (n0 + row) * dim + q * 4);
-        float* d = tile + row * (dim + 1) + q * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        *reinterpret_cast<float4*>(tile + row * rs + q * 4) = v;
     }
+    for (int i = threadIdx.x; i < td * dq; i += blockDim.x)
+        *reinterpret_cast<float4*>(wl + i * 4) = *reinterpret_cast<const float4*>(p.w + i * 4);
+    for (int i = threadIdx.x; i < td; i += blockDim.x) bl[i] = p.bias[i];
     __syncthreads();
 
     const int col = threadIdx.x & (FINAL_COLS - 1);
@@ -111,11 +113,17 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
     if (n >= N) return;
     const int b = (int)(n / p.H);
     const int l = (int)(n - (long)b * p.H);
-    const float* arow = tile + col * (dim + 1);
+    const float* arow = tile + col * rs;
     for (int j = jg; j < td; j += 256 / FINAL_COLS) {
         const float* wr = wl + j * dim;
-        float acc = 0.0f;
-        for (int c = 0; c < dim; ++c) acc = fmaf(wr[c], arow[c], acc);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;       // four chains, summed pairwise
+        for (int c = 0; c < dim; c += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + c);
+            const float4 av = *reinterpret_cast<const float4*>(arow + c);
+            a0 = fmaf(wv.x, av.x, a0); a1 = fmaf(wv.y, av.y, a1);
+            a2 = fmaf(wv.z, av.z, a2); a3 = fmaf(wv.w, av.w, a3);
+        }
+        const float acc = (a0 + a1) + (a2 + a3);
         const long idx = n * td + j;
         const float out = acc + bl[j];
         if (p.eps_out != nullptr) p.eps_out[idx] = out;
@@ -146,10 +154,15 @@ struct ProjParams {
     float alpha, one_minus_alpha;
 };
 
-template <int RB>
-__global__ __launch_bounds__(256) void project_kernel(const ProjParams p) {
-    extern __shared__ __attribute__((aligned(16))) float v[];    // [RB][D]
+// One block = RB trajectories, KP waves.  v@P is latency-bound (P = D*D*4 bytes streams through
+// every CU from L2, one dependent-free load per FMA), so the work is spread as wide as it goes:
+// lane dl of wave kp accumulates column d = 64 s + dl over the kp-th slice of k; the KP slices
+// meet in LDS and are added in fixed order.  (4 waves: 11.8 us per call at B=256, D=196.)
+template <int RB, int KP>
+__global__ __launch_bounds__(64 * KP) void project_kernel(const ProjParams p) {
+    extern __shared__ __attribute__((aligned(16))) float v[];    // [RB][D] rows, then [KP][RB][D] partials
     const int D = p.D, H = p.H, n = p.n, m = p.m, td = p.od + p.m;
+    float* part = v + RB * D;
     const int b0 = blockIdx.x * RB;
     const int nstate = (H + 1) * n;
     // gather + de-normalise: [s_0..s_{H-1}, s_{H-1}, a_0..a_{H-1}]  (policies.py:434-448)
@@ -172,29 +185,40 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjParams p) {
         v[e] = val;
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const int dl = threadIdx.x & 63, kp = threadIdx.x >> 6;
+    const int kq = (D + KP - 1) / KP;
+    const int k0 = kp * kq, k1 = min(D, k0 + kq);
+    for (int d = dl; d < D; d += 64) {
         float acc[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) acc[r] = 0.0f;
-        for (int k = 0; k < D; ++k) {
-            const float pk = p.P[(long)k * D + d];
+        const float* pc = p.P + d;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            const float pk = pc[(long)k * D];
 #pragma unroll
             for (int r = 0; r < RB; ++r) acc[r] = fmaf(v[r * D + k], pk, acc[r]);
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int b = b0 + r;
-            if (b >= p.B) continue;
-            const float blended = p.alpha * acc[r] + p.one_minus_alpha * v[r * D + d];
-            float* xb = p.x + (long)b * H * td;
-            if (d < nstate) {
-                const int ts = d / n, k = d - ts * n;
-                if (ts < H) xb[ts * td + k] = (blended - p.obs_mean[k]) / p.obs_std[k];
-            } else {
-                const int dd = d - nstate;
-                const int ts = dd / m, k = dd - ts * m;
-                xb[ts * td + p.od + k] = (blended - p.act_mean[k]) / p.act_std[k];
-            }
+        for (int r = 0; r < RB; ++r) part[(kp * RB + r) * D + d] = acc[r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < RB * D; e += blockDim.x) {
+        const int r = e / D, d = e - r * D;
+        const int b = b0 + r;
+        if (b >= p.B) continue;
+        float proj = 0.0f;
+#pragma unroll
+        for (int q = 0; q < KP; ++q) proj += part[(q * RB + r) * D + d];
+        const float blended = p.alpha * proj + p.one_minus_alpha * v[r * D + d];
+        float* xb = p.x + (long)b * H * td;
+        if (d < nstate) {
+            const int ts = d / n, k = d - ts * n;
+            if (ts < H) xb[ts * td + k] = (blended - p.obs_mean[k]) / p.obs_std[k];
+        } else {
+            const int dd = d - nstate;
+            const int ts = dd / m, k = dd - ts * m;
+            xb[ts * td + p.od + k] = (blended - p.act_mean[k]) / p.act_std[k];
         }
     }
     // observation channels beyond the physical state are zero-padded (policies.py:475-480)

@@ -304,7 +304,17 @@ class DynamicsAwarePolicy(GuidedPolicy):
         if kind == "quadratic":
             return self.projection_strength * (1 - progress) ** 2
         if kind == "noise_schedule":
-            return torch.sqrt(1 - self.diffusion.betas[t]).item() * self.projection_strength
+            # same fp32 arithmetic as the reference's torch.sqrt(1 - betas[t]).item(), evaluated
+            # on a host copy of the schedule (one device read per schedule, not one sync per t)
+            betas = self.diffusion.betas
+            key = (betas.data_ptr(), betas._version, int(betas.shape[0]))
+            if getattr(self, "_betas_host_key", None) != key:
+                b = betas.detach().to("cpu", torch.float32).numpy()
+                # numpy's float32 sqrt is the IEEE instruction (correctly rounded, like the 0-d
+                # torch op of the reference); torch's vectorised CPU sqrt is not on every host
+                self._betas_host = np.sqrt(np.float32(1.0) - b)
+                self._betas_host_key = key
+            return float(self._betas_host[t]) * self.projection_strength
         raise ValueError(f"Unknown projection schedule: {kind}")
 
     def _projection_state(self) -> ProjectionState:
