@@ -382,3 +382,31 @@ def test_batched_get_actions_matches_per_env_oracle(dev):
     assert pol._batched_cursor == ah + 1                                  # queue exhausted: replan next
     with pytest.raises(ValueError):
         pol.get_actions(np.zeros((N, 3), np.float32))
+
+
+def test_projector_and_system_id_on_the_device(dev):
+    """P built on the GPU equals the host pinv path at PointMaze size and is a
+    rank-(n + H m) orthogonal projector at Door size (D = 2183); the device least-squares fit
+    equals the host fit."""
+    from dynamics_aware_diffusion_amd.dynamics import (ProjectionMatrixBuilder, double_integrator,
+                                                       fit_linear_dynamics)
+    A, B = double_integrator(0.1)
+    b = ProjectionMatrixBuilder(A, B, 4, 2)
+    Pd = b.get_projection_matrix(32, device=dev)
+    assert Pd.device.type == "cuda" and Pd.dtype == torch.float32
+    assert max_abs(Pd.cpu().numpy(), b.get_projection_matrix(32).numpy()) <= 1e-6
+    rng = np.random.default_rng(9)
+    n, m, H = 39, 28, 32
+    A = 0.95 * np.linalg.qr(rng.normal(size=(n, n)))[0]
+    Bm = rng.normal(size=(n, m)) / np.sqrt(n)
+    P = ProjectionMatrixBuilder(A, Bm, n, m).get_projection_matrix(H, device=dev).double()
+    D = (H + 1) * n + H * m
+    assert P.shape == (D, D)
+    assert float((P - P.T).abs().max()) <= 1e-6
+    assert float((P @ P - P).abs().max()) <= 1e-5
+    assert abs(float(P.trace()) - (n + H * m)) <= 1e-2
+    S = rng.normal(size=(5000, n)); U = rng.normal(size=(5000, m))
+    S1 = S @ A.T + U @ Bm.T
+    Ah, Bh = fit_linear_dynamics(S, U, S1)
+    Ad, Bd = fit_linear_dynamics(S, U, S1, device=dev)
+    assert np.abs(Ad - Ah).max() <= 1e-9 and np.abs(Bd - Bh).max() <= 1e-9 and np.abs(Ad - A).max() <= 1e-9

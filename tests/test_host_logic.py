@@ -308,3 +308,74 @@ def test_two_rank_gather_over_gloo(tmp_path, total):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}:\n{out}"
         assert f"rank {r} ok" in out
+
+
+# --------------------------------------------------------------- dynamics package
+def _synthetic_transitions(n_obs=6, n=4, m=2, N=400, noise=0.0, seed=3):
+    from dynamics_aware_diffusion_amd.dynamics import double_integrator
+    A, B = double_integrator(0.1)
+    rng = np.random.default_rng(seed)
+    S = rng.normal(size=(N, n_obs))
+    U = rng.normal(size=(N, m))
+    S1 = rng.normal(size=(N, n_obs))                     # goal columns: unrelated to the dynamics
+    S1[:, :n] = S[:, :n] @ A.T + U @ B.T + noise * rng.normal(size=(N, n))
+    return A, B, S, U, S1
+
+
+def test_least_squares_fit_recovers_the_linear_system():
+    """data_driven.py:75-134: lstsq on [X U]; state_dim keeps the physical columns."""
+    from dynamics_aware_diffusion_amd.dynamics import fit_linear_dynamics, identify_dynamics_from_arrays
+    A, B, S, U, S1 = _synthetic_transitions()
+    A2, B2, q = fit_linear_dynamics(S, U, S1, state_dim=4, return_quality=True)
+    assert np.abs(A2 - A).max() <= 1e-12 and np.abs(B2 - B).max() <= 1e-12
+    assert q["r_squared"] > 1 - 1e-12 and q["mean_prediction_error"] < 1e-12
+    # the same numbers as numpy's lstsq on the stacked regressors (the reference's formulation)
+    theta = np.linalg.lstsq(np.hstack([S[:, :4], U]), S1[:, :4], rcond=None)[0]
+    assert np.array_equal(A2, theta[:4].T) and np.array_equal(B2, theta[4:].T)
+    A3, B3, n, m = identify_dynamics_from_arrays(S, U, S1, state_dim=4)
+    assert (n, m) == (4, 2) and np.array_equal(A3, A2)
+    # full observation when no state_dim is given (6 x 6 system)
+    A6, B6 = fit_linear_dynamics(S, U, S1)
+    assert A6.shape == (6, 6) and B6.shape == (6, 2)
+    with pytest.raises(ValueError):
+        fit_linear_dynamics(S, U[:-1], S1)
+    with pytest.raises(ValueError):
+        fit_linear_dynamics(S[:3], U[:3], S1[:3])
+
+
+def test_registry_and_episode_helpers():
+    from dynamics_aware_diffusion_amd import dynamics as dyn
+    assert dyn.state_dim_for_env("PointMaze_UMaze-v3") == 4
+    assert dyn.state_dim_for_env("HalfCheetah-v5") == 17
+    assert dyn.state_dim_for_env("AdroitHandDoor-v1") is None          # full observation (n = 39)
+    A, B, n, m = dyn.get_dynamics_for_env("PointMaze_UMaze-v3")        # no data: analytical model
+    A0, B0 = dyn.double_integrator(0.1)
+    assert (n, m) == (4, 2) and np.array_equal(A, A0) and np.array_equal(B, B0)
+    At, Bt, S, U, S1 = _synthetic_transitions()
+    A2, B2, n2, m2 = dyn.get_dynamics_for_env("pointmaze", transitions=(S, U, S1))
+    assert (n2, m2) == (4, 2) and np.abs(A2 - At).max() <= 1e-12
+    with pytest.raises(ValueError):
+        dyn.get_dynamics_for_env("HalfCheetah-v5")                     # needs data
+    with pytest.raises(ImportError):
+        dyn.identify_dynamics_from_data("D4RL/pointmaze/umaze-v2")
+    obs = [np.arange(12.0).reshape(4, 3), np.arange(9.0).reshape(3, 3)]
+    act = [np.ones((3, 2)), np.ones((2, 2))]
+    s, a, s1 = dyn.transitions_from_episodes(obs, act, state_dim=2)
+    assert s.shape == (5, 2) and a.shape == (5, 2) and np.array_equal(s1[0], obs[0][1, :2])
+    with pytest.raises(ValueError):
+        dyn.transitions_from_episodes([np.zeros((3, 3))], [np.zeros((3, 2))])
+
+
+def test_qr_projector_equals_the_pinv_projector():
+    """The device path's algorithm (P = Q Q^T) against the reference's F pinv(F), on the CPU."""
+    from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder, double_integrator
+    A, B = double_integrator(0.1)
+    b = ProjectionMatrixBuilder(A, B, 4, 2)
+    for H in (8, 32):
+        assert float((b.projection_matrix_on_device(H, "cpu") - b.get_projection_matrix(H)).abs().max()) <= 1e-6
+    rng = np.random.default_rng(5)
+    A = 0.9 * np.linalg.qr(rng.normal(size=(7, 7)))[0]
+    B = rng.normal(size=(7, 3))
+    b = ProjectionMatrixBuilder(A, B, 7, 3)
+    P = b.projection_matrix_on_device(16, "cpu")
+    assert float((P - b.get_projection_matrix(16)).abs().max()) <= 1e-6 and b.verify_projection(P)
