@@ -254,6 +254,11 @@ def test_projection_vs_reference(dev):
     stats = [torch.from_numpy(v) for v in (norm.obs_mean, norm.obs_std, norm.action_mean, norm.action_std)]
     want = op.apply_projection(torch.from_numpy(xs), P, 1.0, 4, 4, *stats)
     assert max_abs(y.cpu().numpy(), want.numpy()) <= 5e-6
+    # beyond one wave of blocks the kernel takes four rows per block (600 = 150 blocks)
+    xs = synth_normal((600, cases.H, 6))
+    y = pol.apply_projection(torch.from_numpy(xs).to(dev), 0)
+    want = op.apply_projection(torch.from_numpy(xs), P, 1.0, 4, 4, *stats)
+    assert max_abs(y.cpu().numpy(), want.numpy()) <= 5e-6
     # error parity: observation_dim != state_dim raises like the reference's broadcast
     bad = DynamicsAwarePolicy(diff, projection_matrix=P, normalizer=cases.NormalizerStub(6, 2),
                               state_dim=4, observation_dim=6, action_dim=2, horizon=cases.H)
