@@ -156,6 +156,8 @@ def main() -> None:
     ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"],
                     help="conv arithmetic: exact fp32 MFMA, or split-f16 operands (3 f16 MFMAs per "
                          "product block, fp32 accumulation; same parity gates)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the sampling loop as one hipGraph (auto: batches <= 32, which are launch-bound)")
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the second pass with the other conv arithmetic")
     ap.add_argument("--inflight", type=int, default=1,
@@ -194,7 +196,8 @@ def main() -> None:
         T = 500
     td = od + ad
     policy, diff, cond, state = build_policy(arch, device, args.precision, args.workload)
-    diff.use_graph = batch <= 32          # small batches are launch-bound: replay one hipGraph
+    # small batches are launch-bound: replay one hipGraph
+    diff.use_graph = batch <= 32 if args.graph == "auto" else args.graph == "on"
     gathered = torch.empty(world * batch, 32, td, device=device) if world > 1 else None
 
     def one_step(k: int):
@@ -342,7 +345,7 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "arch": arch, "batch_per_gpu": batch,
                        "global_batch": world * batch, "horizon": 32, "denoise_steps": T,
-                       "rng": "in-kernel philox", "conv_arithmetic": args.precision + (" (exact fp32 MFMA)" if args.precision == "fp32" else " (split-f16 operands, fp32 accumulate)"), "hipgraph": bool(batch <= 32), "sharding": f"batch x{world}, gather at end", "loops_in_flight": args.inflight},
+                       "rng": "in-kernel philox", "conv_arithmetic": args.precision + (" (exact fp32 MFMA)" if args.precision == "fp32" else " (split-f16 operands, fp32 accumulate)"), "hipgraph": bool(diff.use_graph), "sharding": f"batch x{world}, gather at end", "loops_in_flight": args.inflight},
             "roofline": roof, "cpu_baseline": base, "alt_precision": alt,
         }
         print(json.dumps(out))

@@ -77,6 +77,12 @@ if sq:
     if tot.get("SQ_WAVE_CYCLES"):
         wc = tot["SQ_WAVE_CYCLES"]
         summary["sq_ratios"] = {k: tot[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in tot}
+    if tot.get("SQ_BUSY_CU_CYCLES") and tot.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # MFMA utilisation: matrix-pipe busy cycles (summed over the 4 SIMDs of a CU) over the
+        # cycles the CU had work — the in-kernel share of time the matrix cores were issuing
+        summary["mfma_util"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * tot["SQ_BUSY_CU_CYCLES"])
+    if tot.get("SQ_LDS_IDX_ACTIVE"):
+        summary["lds_bank_conflict_frac"] = tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / tot["SQ_LDS_IDX_ACTIVE"]
 # ---- the split-f16 arithmetic (bench.py --precision f16x3): its own stats table and traffic
 x3stats = one("x3_trace/**/*_kernel_stats.csv")
 if x3stats:
