@@ -106,6 +106,8 @@ struct ConvParams {
     int32_t kslices;     // blocks per output tile (1 = off)
     int32_t chunks_per_slice;
     float c1, c2;        // split-f16 kernels: out = acc_hh * c1 + acc_cross * c2  (2^-s, 2^-s-11)
+    uint64_t xswz;       // 16 x 4 bits: sample s of the tile sits xswz[s] 16-byte slots further right
+                         // in the X stage (bank-conflict-free ds_read_b128 at L <= 16; 0 = plain)
     float* slab;         // [tiles][kslices][BN*BM] fp32 partial tiles (workspace)
     unsigned* counters;  // [tiles] arrival tickets, zero between launches
 #ifdef DAD_STAMPS
@@ -165,6 +167,16 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// Activation rows in LDS and bank conflicts.  A wave's ds_read_b128 is served in four groups of
+// 16 lanes; a group is conflict-free when its lanes hit 16 different 16-byte slots of the 256-byte
+// bank row.  Lane n reads row  s*SEG + l  (sample s, position l), rows are an odd number of slots
+// apart, so 16 consecutive rows are fine — but samples of L <= 16 positions are separated by their
+// halo rows, and rows of different samples alias (measured: 35 % of all LDS cycles were 2-way
+// conflicts).  Cure: sample s is stored shifted right by d(s) slots, d in [0, 16), chosen on the
+// host so that every group sees 16 distinct slots (ConvParams::xswz; dad_lib.hip find_xswz).  A
+// shift moves a sample's trailing halo over the next sample's leading halo — zeros over zeros;
+// the search keeps it off the neighbour's real rows.  The stage grows by 15 slots.
+constexpr int kXSwzPad = 64;    // floats
 // Rows of the X stage: every sample of the tile with its zero halo.
 __host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
     return (BN / Lout) * (Lin + 2 * (taps / 2));
@@ -173,7 +185,7 @@ __host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
 __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int taps, int Lin,
                                                   int Lout, int SK) {
     const size_t kp = KC + 4;
-    const size_t stage = (size_t)conv_xrows(BN, Lin, Lout, taps) * kp +
+    const size_t stage = (size_t)conv_xrows(BN, Lin, Lout, taps) * kp + kXSwzPad +
                          (size_t)taps * BM * kp;
     const size_t epi = (size_t)SK * BN * (BM + 4) + 64;
     const size_t k = 2 * stage;
@@ -199,6 +211,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     static_assert(KC % KU == 0 && G % SK == 0 && GW >= 1, "K chunk must split evenly over the SK waves");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // Vector accesses go through these views with an index in vector units: every offset below
+    // is a multiple of 4 floats by construction, but only the index form lets hipcc see it (one
+    // runtime term of unknown low bits and it splits each ds_read_b128 into dword pairs — which
+    // doubled the split-f16 kernels' time when the per-sample slot shift was added).
+    float4* const smem4 = reinterpret_cast<float4*>(smem);
+    float2* const smem2 = reinterpret_cast<float2*>(smem);
 #ifdef DAD_ABLATE_NULL
     if (p.B > 0) return;
 #endif
@@ -232,8 +250,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int M = p.M;
     const int nvalid = min(SPT, p.B - s0);
 
-    const int XF = XROWS * KP;
+    const int XF = XROWS * KP + kXSwzPad;
     const int STAGE = XF + TAPS * BM * KP;       // floats per stage: [X rows][W rows]
+    const int STAGE4 = STAGE >> 2;               // the same in float4 units (every term is a multiple of 4)
 
 
     // A operand (activations): lane's GEMM row n -> LDS row of tap 0
@@ -241,7 +260,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     // Transposed conv as two 2-tap phases: even outputs read positions (l-1, l), odd outputs
     // (l, l+1); the M tile's phase shifts the first row by one.
     const int phase_shift = (TAPS == 2 && p.interleave && m0 >= (p.M >> 1)) ? 1 : 0;
-    const int arow = ((n_loc >> p.lshift) * SEG + (n_loc & (Lout - 1)) * STRIDE + phase_shift) * KP + 4 * h;
+    const int arow = ((n_loc >> p.lshift) * SEG + (n_loc & (Lout - 1)) * STRIDE + phase_shift) * KP + 4 * h +
+                     (int)((p.xswz >> (4 * (n_loc >> p.lshift))) & 15) * 4;
     // B operand (weights): lane's output channel
     const int brow = XF + (tm * 32 + l32) * KP + 4 * h;
 
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int mm = row - tap * BM;
         const int sub = q / GQ;
         w_goff[i] = ((sub * TAPS + tap) * M + m0 + mm) * KG + (q - sub * GQ) * 4;
-        w_loff[i] = XF + row * KP + q * 4;
+        w_loff[i] = (XF + row * KP + q * 4) >> 2;         // float4 units
     }
 #pragma unroll
     for (int i = 0; i < X_PER_T; ++i) {
@@ -297,7 +317,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         x_q4[i] = q * 4;
         // split-f16 rows: per 16-channel unit [8 floats of hi halves | 8 floats of lo halves]
         const int qoff = X3 ? (q >> 2) * 16 + (q & 3) * 2 : q * 4;
-        x_loff[i] = e < xrows_real * KQ ? (s * SEG + PAD + l) * KP + qoff : -1;
+        // float4 units (fp32 rows) or float2 units (split-f16 rows: a float4 becomes 8 bytes of hi
+        // halves and, 8 floats further, 8 bytes of lo halves)
+        const int xo = (s * SEG + PAD + l) * KP + qoff + (int)((p.xswz >> (4 * s)) & 15) * 4;
+        x_loff[i] = e < xrows_real * KQ ? (X3 ? xo >> 1 : xo >> 2) : -1;
     }
     DAD_PSTAMP(6);
     const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
@@ -317,10 +340,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     // round trip exposed per unit.  The last two chunks run as peeled variants.)
     constexpr int NLD = W_PER_T + X_PER_T;
     auto item_store = [&](int k, int stage) {
-        const int base = stage * STAGE;
+        const int base4 = stage * STAGE4;
         if (k < W_PER_T) {
             if (W_F4 % NT == 0 || tid + k * NT < W_F4)
-                *reinterpret_cast<float4*>(&smem[base + w_loff[k]]) = wreg[k];
+                smem4[base4 + w_loff[k]] = wreg[k];
         } else {
             const int i = k - W_PER_T;
             if (x_loff[i] >= 0) {
@@ -329,10 +352,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
                 if constexpr (X3) {
                     float2 hi, lo;
                     split_f16x4(v, hi, lo);
-                    *reinterpret_cast<float2*>(&smem[base + x_loff[i]]) = hi;
-                    *reinterpret_cast<float2*>(&smem[base + x_loff[i] + 8]) = lo;
+                    smem2[base4 * 2 + x_loff[i]] = hi;
+                    smem2[base4 * 2 + x_loff[i] + 4] = lo;
                 } else {
-                    *reinterpret_cast<float4*>(&smem[base + x_loff[i]]) = v;
+                    smem4[base4 + x_loff[i]] = v;
                 }
             }
         }
@@ -384,15 +407,15 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     // behind the barrier while those MFMAs run, so the matrix pipe does not drain at the barrier.
     constexpr int UW = TAPS * GW;                       // units per wave per chunk
     const int koff = ks * (GW * KU);                    // this wave's units in a chunk
-    const int afrag = arow + koff;
-    const int bfrag = brow + koff;
+    const int afrag4 = (arow + koff) >> 2;              // float4 units: the constant parts of the
+    const int bfrag4 = (brow + koff) >> 2;              // fragment addresses fold into ds_read offsets
     auto frag_a = [&](int stage, int u, int lo) -> float4 {   // lo = 8: the residual halves (X3)
         const int tap = u / GW, gw = u - tap * GW;
-        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + afrag + tap * KP + gw * KU + lo]);
+        return smem4[stage * STAGE4 + afrag4 + tap * (KP / 4) + gw * (KU / 4) + lo / 4];
     };
     auto frag_b = [&](int stage, int u, int lo) -> float4 {
         const int tap = u / GW, gw = u - tap * GW;
-        return *reinterpret_cast<const float4*>(&smem[stage * STAGE + bfrag + tap * BM * KP + gw * KU + lo]);
+        return smem4[stage * STAGE4 + bfrag4 + tap * (BM * KP / 4) + gw * (KU / 4) + lo / 4];
     };
 
     // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
@@ -474,8 +497,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             const int hr = i / KP4, c4 = i - hr * KP4;
             const int s = hr / (2 * PAD), j = hr - s * (2 * PAD);
             const int row = s * SEG + (j < PAD ? j : Lin + j);
-            *reinterpret_cast<float4*>(&smem[row * KP + c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&smem[STAGE + row * KP + c4 * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int at = row * KP + c4 * 4 + (int)((p.xswz >> (4 * s)) & 15) * 4;
+            smem4[at >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            smem4[STAGE4 + (at >> 2)] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     DAD_PSTAMP(2);

@@ -8,8 +8,10 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,6 +24,7 @@ namespace {
 thread_local char g_err[1024] = "";
 int g_force_tile = -1;      // dad_debug_set_tile: tuning / test hook
 bool g_split_enabled = true;
+bool g_xswz_enabled = getenv("DAD_NO_XSWZ") == nullptr;     // A/B switch for the LDS row shifts
 #ifdef DAD_STAMPS
 unsigned long long* g_stamps = nullptr;
 #endif
@@ -597,6 +600,57 @@ int choose_tile(const ConvOp& op, int batch) {
     return -1;
 }
 
+// Per-sample slot shifts of the X stage (conv_gemm.hpp, "Activation rows in LDS and bank
+// conflicts").  Depth-first over the samples of a block tile: d(s) in [0, 16) such that in every
+// 32-row wave tile both 16-lane groups of ds_read_b128 see 16 distinct slots, and no sample is
+// pushed onto its neighbour's real rows (d(s) - d(s+1) <= pad * slots-per-row).  Returns 0 (plain
+// layout — correct, just slower) when L >= 32, when there is no halo, or when nothing is found.
+uint64_t find_xswz(int L, int stride, int pad, int kp4, int BN) {
+    if (L >= 32 || pad == 0 || BN / L > 16) return 0;
+    static std::map<std::vector<int>, uint64_t> cache;
+    static std::mutex cache_lock;
+    std::lock_guard<std::mutex> hold(cache_lock);
+    const std::vector<int> key{L, stride, pad, kp4, BN};
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int S = BN / L, seg = L * stride + 2 * pad, per = 32 / L;
+    std::vector<int> d(S, 0);
+    // conflicts among the lanes whose samples are already placed (samples < upto)
+    auto ok_prefix = [&](int upto) {
+        for (int tn = 0; tn * per < upto; ++tn)
+            for (const auto& g : groups) {
+                unsigned seen = 0;
+                for (int lane : g) {
+                    const int n = tn * 32 + lane, sm = n / L, l = n % L;
+                    if (sm >= upto) continue;
+                    const unsigned bit = 1u << (((sm * seg + l * stride) * kp4 + d[sm]) & 15);
+                    if (seen & bit) return false;
+                    seen |= bit;
+                }
+            }
+        return true;
+    };
+    long budget = 300000;                           // node budget: the search is a one-off per shape
+    std::function<bool(int)> place = [&](int sm) -> bool {
+        if (sm == S) return true;
+        for (int v = 0; v < 16; ++v) {
+            if (--budget < 0) return false;
+            if (sm > 0 && d[sm - 1] - v > pad * kp4) continue;
+            d[sm] = v;
+            if (ok_prefix(sm + 1) && place(sm + 1)) return true;
+        }
+        d[sm] = 0;
+        return false;
+    };
+    uint64_t packed = 0;
+    if (place(0))
+        for (int sm = 0; sm < S; ++sm) packed |= (uint64_t)d[sm] << (4 * sm);
+    cache[key] = packed;
+    return packed;
+}
+
 // Grid-level split-K: when a layer has too few output tiles to cover the chip (small batches;
 // the deepest levels of the wide nets), several blocks share a tile and split its K chunks.
 struct SplitPlan { int kslices, chunks_per_slice; long slab_floats; };
@@ -662,6 +716,11 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.slab = ws + m->plan.floats_per_sample * (long)batch;     // scratch behind the activations
     p.counters = m->d_counters;
     p.c1 = op.c1; p.c2 = op.c2;
+    {
+        const TileCfg& tc = kTiles[cfg];
+        const int kc = eff_kc(tc.KC, tc.BM, op.taps, tc.SK, op.x3);
+        p.xswz = g_xswz_enabled ? find_xswz(op.Lout, op.stride, op.taps / 2, (kc + 4) / 4, tc.BN) : 0;
+    }
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;     // tuning aid
     if (trace)
         fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d tile=%d (%dx%d SK%d) kslices=%d\n", op.name.c_str(),
