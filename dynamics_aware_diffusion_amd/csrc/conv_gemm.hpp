@@ -1,6 +1,8 @@
 // conv_gemm.hpp — Conv1d / ConvTranspose1d of the TemporalUnet as an implicit GEMM on the
-// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32), with the whole Conv1dBlock tail
-// (bias -> GroupNorm(8) -> Mish -> + time embedding -> + residual) fused in the epilogue.
+// gfx950 matrix cores — exact fp32 products (v_mfma_f32_32x32x2_f32) or, template parameter X3,
+// split-f16 operands (three v_mfma_f32_32x32x16_f16 per product block, fp32 accumulation) —
+// with the whole Conv1dBlock tail (bias -> GroupNorm(8) -> Mish -> + time embedding ->
+// + residual) fused in the epilogue.
 //
 // Replaces, per launch, the reference's  F.conv1d / F.conv_transpose1d -> F.group_norm ->
 // F.mish -> add chains of m_diffuser/models/temporal_unet.py:57-76 (Conv1dBlock),
@@ -14,7 +16,7 @@
 //   * im2col is never materialised: a K-chunk of KC input channels is staged in LDS as one
 //     row per (sample, position) with PAD zero rows on both sides of every sample; tap j of
 //     the filter is then "+ j rows" on the LDS address.
-//   * weights are pre-packed on the host as [C_in/KC][tap][M][KC] so that both MFMA operands
+//   * weights are pre-packed on the host as [C_in/16][tap][M][16] so that both MFMA operands
 //     are fetched with one ds_read_b128 per four MFMAs: lane half h of the wave owns input
 //     channels 4h..4h+3 of every 8-channel group (any bijection of K onto (step, half) is a
 //     valid summation order as long as both operands use it).
