@@ -194,3 +194,17 @@ N_GET_ACTION_CALLS = 12
 
 def glue_observations() -> np.ndarray:
     return synth.normal_like(51, "glue.obs", (N_GET_ACTION_CALLS, 4))
+
+
+# --------------------------------------------------------------------------- system identification
+def sysid_transitions(case: str = "sysid", n_obs: int = 6, n: int = 4, m: int = 2, N: int = 300):
+    """(states, actions, next_states) of a noisy double integrator inside 6-column observations
+    (columns 4..5 play PointMaze's goal: unrelated to the dynamics) — data_driven.py:75-134."""
+    dt = 0.1
+    A = np.array([[1, 0, dt, 0], [0, 1, 0, dt], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    B = np.array([[0.5 * dt * dt, 0], [0, 0.5 * dt * dt], [dt, 0], [0, dt]], dtype=np.float64)
+    S = synth.normal_like(71, case + ".s", (N, n_obs)).astype(np.float64)
+    U = synth.normal_like(71, case + ".u", (N, m)).astype(np.float64)
+    S1 = synth.normal_like(71, case + ".s1", (N, n_obs)).astype(np.float64)
+    S1[:, :n] = S[:, :n] @ A.T + U @ B.T + 1e-3 * synth.normal_like(71, case + ".e", (N, n)).astype(np.float64)
+    return S, U, S1

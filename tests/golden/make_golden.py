@@ -307,6 +307,19 @@ def gen_glue():
     save("glue", **out)
 
 
+def gen_sysid():
+    """fit_linear_dynamics of the reference (dynamics/data_driven.py:75-134) on synthetic
+    transitions.  The module imports minari at the top and never uses it in this function; minari
+    is not installed here, so an empty placeholder module stands in for the import."""
+    sys.modules.setdefault("minari", types.ModuleType("minari"))
+    from m_diffuser.dynamics.data_driven import fit_linear_dynamics
+    S, U, S1 = cases.sysid_transitions()
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        A4, B4 = fit_linear_dynamics(S, U, S1, state_dim=4)
+        A6, B6 = fit_linear_dynamics(S, U, S1)
+    save("sysid", A4=A4, B4=B4, A6=A6, B6=B6)
+
+
 def gen_keys():
     """state_dict key -> shape of the reference GaussianDiffusion for every architecture."""
     import json
@@ -329,7 +342,7 @@ SECTIONS = {
     "keys": gen_keys,
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
     "forward": gen_forward, "loops": gen_loops, "guidance": gen_guidance,
-    "projection": gen_projection, "glue": gen_glue,
+    "projection": gen_projection, "glue": gen_glue, "sysid": gen_sysid,
 }
 
 if __name__ == "__main__":

@@ -166,3 +166,16 @@ def test_projection_matrices_and_apply():
     with pytest.raises(RuntimeError):
         op.apply_projection(torch.zeros(2, 32, 8), P, 0.5, 4, 6,
                             torch.zeros(6), torch.ones(6), torch.zeros(2), torch.ones(2))
+
+
+def test_system_identification_vs_reference():
+    """dynamics.fit_linear_dynamics against the reference's own least-squares fit
+    (data_driven.py:75-134) on the same synthetic transitions."""
+    from dynamics_aware_diffusion_amd.dynamics import fit_linear_dynamics
+    g = golden("sysid")
+    S, U, S1 = cases.sysid_transitions()
+    A4, B4 = fit_linear_dynamics(S, U, S1, state_dim=4)
+    A6, B6 = fit_linear_dynamics(S, U, S1)
+    for got, key in ((A4, "A4"), (B4, "B4"), (A6, "A6"), (B6, "B6")):
+        assert got.shape == g[key].shape
+        assert max_abs(got, g[key]) <= 1e-12, key
