@@ -185,16 +185,22 @@ __host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
 }
 // LDS floats of one block (the host sizes the dynamic allocation with the same formula).
 __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int taps, int Lin,
-                                                  int Lout, int SK) {
+                                                  int Lout, int SK, bool bdir = false) {
     const size_t kp = KC + 4;
     const size_t stage = (size_t)conv_xrows(BN, Lin, Lout, taps) * kp + kXSwzPad +
-                         (size_t)taps * BM * kp;
+                         (bdir ? 0 : (size_t)taps * BM * kp);
     const size_t epi = (size_t)SK * BN * (BM + 4) + 64;
     const size_t k = 2 * stage;
     return k > epi ? k : epi;
 }
 
-template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED, bool X3 = false>
+// BDIR (split-f16 only): the B operand (weights) goes global -> registers directly, no LDS.  For
+// tiles one wave-tile wide (BN = 32) every weight fragment is used by exactly one wave, so staging
+// it through LDS buys no sharing and only costs capacity: the 256-row tile of the 2048-channel
+// layers (GroupNorm groups of 256 channels) cannot double-buffer a 16-channel split-f16 stage in
+// 160 KiB.  The fragments roll like the staged items: those of unit u are consumed by the unit's
+// MFMAs and the registers immediately receive the same unit of the next chunk.
+template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED, bool X3 = false, bool BDIR = false>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32(const ConvParams p) {
     constexpr int TMW = BM / 32;                 // wave tiles along M
     constexpr int TNW = BN / 32;                 // wave tiles along N
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     constexpr int KG = KC < 16 ? KC : 16;        // packing granule of the weights
     constexpr int NSUB = KC / KG;                // packed granules per chunk
     static_assert(KC % KU == 0 && G % SK == 0 && GW >= 1, "K chunk must split evenly over the SK waves");
+    static_assert(!BDIR || (X3 && BN == 32 && SK == 1 && !RAGGED && KC >= 16), "direct-B tiles");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Vector accesses go through these views with an index in vector units: every offset below
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int nvalid = min(SPT, p.B - s0);
 
     const int XF = XROWS * KP + kXSwzPad;
-    const int STAGE = XF + TAPS * BM * KP;       // floats per stage: [X rows][W rows]
+    const int STAGE = XF + (BDIR ? 0 : TAPS * BM * KP);   // floats per stage: [X rows][W rows]
     const int STAGE4 = STAGE >> 2;               // the same in float4 units (every term is a multiple of 4)
 
 
@@ -285,15 +292,16 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 
     // ---- staging: global -> registers (prefetch) -> LDS ---------------------------------
     constexpr int W_F4 = TAPS * BM * KC / 4;
-    constexpr int W_PER_T = (W_F4 + NT - 1) / NT;
+    constexpr int W_PER_T = BDIR ? 0 : (W_F4 + NT - 1) / NT;   // staged W items (none in direct-B mode)
+    constexpr int W_ARR = W_PER_T ? W_PER_T : 1;
     constexpr int KQ = KC / 4;                              // float4 per row
     constexpr int X_F4_MAX = BN * STRIDE * KQ;              // SPT*Lin == BN*STRIDE rows
     constexpr int X_PER_T = (X_F4_MAX + NT - 1) / NT;
     const int xrows_real = SPT * Lin;
-    float4 wreg[W_PER_T];
+    float4 wreg[W_ARR];
     float4 xreg[X_PER_T];
     // Per-thread staging addresses are chunk-invariant up to a uniform stride: computed once.
-    int w_goff[W_PER_T], w_loff[W_PER_T];                  // global / LDS float offsets (W)
+    int w_goff[W_ARR], w_loff[W_ARR];                      // global / LDS float offsets (W)
     int x_grow[X_PER_T], x_q4[X_PER_T], x_loff[X_PER_T];   // global row, channel quad, LDS (X)
     constexpr int GQ = KG / 4;                              // float4 per packed row
 #pragma unroll
@@ -419,6 +427,16 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int tap = u / GW, gw = u - tap * GW;
         return smem4[stage * STAGE4 + bfrag4 + tap * (BM * KP / 4) + gw * (KU / 4) + lo / 4];
     };
+    // direct-B mode: this lane's weight fragments of every unit of one chunk (hi, lo), straight from
+    // the packed image  [granule][tap][M][16 floats = 16 hi halves | 16 lo halves]
+    float4 breg[BDIR ? 2 * UW : 1];
+    const float* bsrc = p.w + ((long)(m0 + tm * 32 + l32) * 16 + 4 * h);
+    auto bload = [&](int u, int chunk) {
+        const int tap = u / GW, gw = u - tap * GW;
+        const float* q = bsrc + (long)chunk * w_chunk_stride + (long)((gw * TAPS + tap) * M) * 16;
+        breg[2 * u] = ldg4(q);
+        breg[2 * u + 1] = ldg4(q + 8);
+    };
 
     // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
     // After the LDS exchange each thread owns F4PL float4 (4 channels x 1 position) of one
@@ -486,6 +504,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     DAD_PSTAMP(7);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) item_load(k, c_begin);   // first global loads fly while LDS is zeroed
+    if constexpr (BDIR) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) bload(u, c_begin);
+    }
     if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }   // younger than the stage loads: not waited with them
     DAD_PSTAMP(1);
     // Zero the halo rows of both X stages once (PAD rows on either side of every sample).  Real
@@ -521,15 +543,19 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     // split-f16: a unit is 16 channels = 3 v_mfma_f32_32x32x16_f16 (hi*hi into acc, the two cross
     // terms into acc2 / acc3, which carry a factor 2^11).
     // (DAD_ABLATE_* exist only in timing-only diagnostic builds: wrong results by design.)
-    float4 ah = frag_a(0, 0, 0), bh = frag_b(0, 0, 0);
+    float4 ah = frag_a(0, 0, 0), bh = ah;
+    if constexpr (!BDIR) bh = frag_b(0, 0, 0);
     float4 al = ah, bl = bh;
-    if constexpr (X3) { al = frag_a(0, 0, 8); bl = frag_b(0, 0, 8); }
+    if constexpr (X3) {
+        al = frag_a(0, 0, 8);
+        if constexpr (!BDIR) bl = frag_b(0, 0, 8);
+    }
     DAD_STAMP(1);
     DAD_CLOCK(6);
 #ifndef DAD_ABLATE_STAGE
 #define DAD_ROLL(STORE, LOAD)                                                                    \
     _Pragma("unroll") for (int k = 0; k < NLD; ++k) {                                            \
-        if ((k * UW) / NLD != u) continue;                                                       \
+        if ((BDIR ? UW - 1 : (k * UW) / NLD) != u) continue;   /* direct-B: after the B loads */    \
         if (STORE) item_store(k, cur ^ 1);                                                       \
         if (LOAD) item_load(k, ch + 2);                                                          \
     }
@@ -543,13 +569,18 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #endif
 #ifndef DAD_ABLATE_LDSREAD
 #define DAD_READ(ST, U)                                                                          \
-    nah = frag_a(ST, U, 0); nbh = frag_b(ST, U, 0);                                              \
-    if constexpr (X3) { nal = frag_a(ST, U, 8); nbl = frag_b(ST, U, 8); }
+    nah = frag_a(ST, U, 0);                                                                      \
+    if constexpr (X3) nal = frag_a(ST, U, 8);                                                    \
+    if constexpr (!BDIR) {                                                                       \
+        nbh = frag_b(ST, U, 0);                                                                  \
+        if constexpr (X3) nbl = frag_b(ST, U, 8);                                                \
+    }
 #else
 #define DAD_READ(ST, U)
 #endif
 #ifndef DAD_ABLATE_MFMA
 #define DAD_MFMA()                                                                               \
+    if constexpr (BDIR) { bh = breg[2 * u]; bl = breg[2 * u + 1]; }                              \
     if constexpr (X3) {                                                                          \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),              \
                                                      __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);  \
@@ -582,6 +613,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             __builtin_amdgcn_sched_barrier(0);                                                   \
             DAD_MFMA()                                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                   \
+            if constexpr (BDIR) { if (STORE) bload(u, ch + 1); }                                 \
             ah = nah; al = nal; bh = nbh; bl = nbl;                                              \
         }                                                                                        \
     }

@@ -67,6 +67,7 @@ struct ConvOp {
     int temb_off;            // offset into the per-t table, or -1
     int kc = 16;             // K chunk the weights are packed for (8 when C_out/8 == 256)
     bool x3 = false;         // weights packed as split-f16 images (dad_model_set_precision)
+    bool bdir = false;       // x3 on the wide tile: weight fragments go global -> registers
     float c1 = 1.0f, c2 = 0.0f;   // x3: output scales 2^-s and 2^-(s+11)
     // device tensors (owned by the model)
     float* d_w = nullptr;
@@ -469,7 +470,8 @@ template <> struct Tile<7> { static constexpr int BM = 64, BN = 64, SK = 2, KC =
 // barriers (128 channels; 64 for the 128-row tile, whose stage would not fit LDS twice).
 // Split-f16 kernels consume 16 channels per unit: the chunk must give every split-K wave a unit.
 constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false) {
-    return (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128)
+    return (x3 && cfg_kc == 8)         ? 32          // wide tile, direct-B split-f16 kernel
+           : (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128)
            : (x3 && cfg_kc < 16 * sk)  ? 16 * sk
                                        : cfg_kc;
 }
@@ -478,15 +480,19 @@ template <int CFG, int TAPS, int STRIDE, bool X3>
 int launch_conv_t(ConvParams& p, hipStream_t st) {
     using T = Tile<CFG>;
     constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3);
+    constexpr bool BDIR = X3 && T::KC == 8;        // wide tile: weight fragments straight from global
     const int cin = p.cin0 + p.cin1;
     const bool ragged = (p.cin0 & 3) != 0 || (p.cin1 & 3) != 0 || p.cin0 % KC != 0 || cin % KC != 0;
     if (ragged && !(STRIDE == 1 && (TAPS == 5 || TAPS == 1)))
         return fail(DAD_E_INVALID, "channel count %d+%d needs the general staging path, which exists "
                     "for stride-1 5-tap and 1x1 convs only", p.cin0, p.cin1);
-    auto kern = (ragged && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
-                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true, X3>
-                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3>;
-    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, KC, TAPS, p.Lin, p.Lout, T::SK) * sizeof(float);
+    if (BDIR && ragged)
+        return fail(DAD_E_INVALID, "the direct-B split-f16 kernel needs whole 32-channel chunks (%d+%d)", p.cin0, p.cin1);
+    auto kern = BDIR ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR>
+                : (ragged && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
+                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true && !BDIR, X3, BDIR>
+                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR>;
+    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, KC, TAPS, p.Lin, p.Lout, T::SK, BDIR) * sizeof(float);
     const int spt = T::BN / p.Lout;
     p.ntiles_n = (p.B + spt - 1) / spt;
     if (p.ntiles_n > 65535) return fail(DAD_E_INVALID, "batch too large for one launch (%d N tiles)", p.ntiles_n);
@@ -502,13 +508,14 @@ template <int CFG, int TAPS, int STRIDE, bool X3>
 hipError_t raise_lds_limit() {
     using T = Tile<CFG>;
     constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3);
+    constexpr bool BDIR = X3 && T::KC == 8;
     hipError_t e = hipFuncSetAttribute(
-        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3>,
+        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR>,
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    if (STRIDE == 1 && (TAPS == 5 || TAPS == 1))
+    if (!BDIR && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
         e = hipFuncSetAttribute(
-            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true, X3>,
+            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true && !BDIR, X3, BDIR>,
             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
@@ -524,6 +531,8 @@ hipError_t raise_lds_limit_cfg() {
         if ((e = raise_lds_limit<CFG, 3, 2, true>()) != hipSuccess) return e;
         if ((e = raise_lds_limit<CFG, 2, 1, true>()) != hipSuccess) return e;
         if ((e = raise_lds_limit<CFG, 1, 1, true>()) != hipSuccess) return e;
+    } else {                                   // wide tile: the direct-B kernel of the GroupNorm'd 5-tap convs
+        if ((e = raise_lds_limit<CFG, 5, 1, true>()) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -557,6 +566,9 @@ int launch_conv_cfg(ConvParams& p, int taps, int stride, bool x3, hipStream_t st
             if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1, true>(p, st);
             if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1, true>(p, st);
         }
+    }
+    if constexpr (Tile<CFG>::KC == 8) {
+        if (x3 && taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, true>(p, st);
     }
     if (x3) return fail(DAD_E_INVALID, "no split-f16 kernel for tile %d taps=%d stride=%d", CFG, taps, stride);
     if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, false>(p, st);
@@ -956,15 +968,21 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     for (ConvOp& op : m->plan.convs) {
         const HostTensor& w = m->raw[op.name + ".weight"];
         const HostTensor& b = m->raw[op.name + ".bias"];
-        std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad, op.kc)
-                                                       : pack_conv(w, op.cin_pad, op.taps, op.kc);
+        // wide-group layers (op.kc == 8) in split-f16 mode use the direct-B kernel: 16-channel
+        // granules like every split image, whole 32-channel chunks, 5-tap stride-1 only
+        const int cin_all = op.cin0 + op.cin1;
+        op.bdir = m->precision == DAD_PREC_F16X3 && op.kc == 8 && op.kind == CONV_K5 &&
+                  (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
+        const int pack_g = op.bdir ? 16 : op.kc;
+        std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad, pack_g)
+                                                       : pack_conv(w, op.cin_pad, op.taps, pack_g);
         // split-f16 operands where the kernels exist for every tile this layer may get: 16-channel
         // granules, and for the strided / transposed convs (no general staging path) whole
         // 64-channel chunks
         const int cin = op.cin0 + op.cin1;
-        op.x3 = m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
-                (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
-                 ((op.cin0 & 63) == 0 && (cin & 63) == 0));
+        op.x3 = op.bdir || (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
+                            (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
+                             ((op.cin0 & 63) == 0 && (cin & 63) == 0)));
         op.c1 = 1.0f; op.c2 = 0.0f;
         if (op.x3) {
             const int sh = split_f16_image(packed);
