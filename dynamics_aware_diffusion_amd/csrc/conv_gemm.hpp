@@ -194,12 +194,14 @@ __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int ta
     return k > epi ? k : epi;
 }
 
-// BDIR (split-f16 only): the B operand (weights) goes global -> registers directly, no LDS.  For
+// BDIR: the B operand (weights) goes global -> registers directly, no LDS.  For
 // tiles one wave-tile wide (BN = 32) every weight fragment is used by exactly one wave, so staging
 // it through LDS buys no sharing and only costs capacity: the 256-row tile of the 2048-channel
 // layers (GroupNorm groups of 256 channels) cannot double-buffer a 16-channel split-f16 stage in
-// 160 KiB.  The fragments roll like the staged items: those of unit u are consumed by the unit's
-// MFMAs and the registers immediately receive the same unit of the next chunk.
+// 160 KiB, and its fp32 stage is limited to 8 channels (a barrier every 20 MFMAs).  The fragments
+// roll like the staged items: those of unit u are consumed by the unit's MFMAs and the registers
+// immediately receive the same unit of the next chunk.  Weights are packed in 16-channel granules
+// for both arithmetics: [granule][tap][M][16 floats] (split-f16: 16 hi halves | 16 lo halves).
 template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED, bool X3 = false, bool BDIR = false>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32(const ConvParams p) {
     constexpr int TMW = BM / 32;                 // wave tiles along M
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     constexpr int KG = KC < 16 ? KC : 16;        // packing granule of the weights
     constexpr int NSUB = KC / KG;                // packed granules per chunk
     static_assert(KC % KU == 0 && G % SK == 0 && GW >= 1, "K chunk must split evenly over the SK waves");
-    static_assert(!BDIR || (X3 && BN == 32 && SK == 1 && !RAGGED && KC >= 16), "direct-B tiles");
+    static_assert(!BDIR || (BN == 32 && SK == 1 && !RAGGED && KC >= 16), "direct-B tiles");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Vector accesses go through these views with an index in vector units: every offset below
@@ -429,13 +431,20 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     };
     // direct-B mode: this lane's weight fragments of every unit of one chunk (hi, lo), straight from
     // the packed image  [granule][tap][M][16 floats = 16 hi halves | 16 lo halves]
-    float4 breg[BDIR ? 2 * UW : 1];
+    constexpr int BPU = X3 ? 2 : 1;                     // fragment registers (float4) per unit
+    float4 breg[BDIR ? BPU * UW : 1];
     const float* bsrc = p.w + ((long)(m0 + tm * 32 + l32) * 16 + 4 * h);
     auto bload = [&](int u, int chunk) {
         const int tap = u / GW, gw = u - tap * GW;
-        const float* q = bsrc + (long)chunk * w_chunk_stride + (long)((gw * TAPS + tap) * M) * 16;
-        breg[2 * u] = ldg4(q);
-        breg[2 * u + 1] = ldg4(q + 8);
+        if constexpr (X3) {                             // unit = one 16-channel granule: hi, lo
+            const float* q = bsrc + (long)chunk * w_chunk_stride + (long)((gw * TAPS + tap) * M) * 16;
+            breg[2 * u] = ldg4(q);
+            breg[2 * u + 1] = ldg4(q + 8);
+        } else {                                        // unit = 8 channels = half a granule
+            const float* q = bsrc + (long)chunk * w_chunk_stride +
+                             (long)(((gw >> 1) * TAPS + tap) * M) * 16 + (gw & 1) * 8;
+            breg[u] = ldg4(q);
+        }
     };
 
     // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
@@ -580,7 +589,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #endif
 #ifndef DAD_ABLATE_MFMA
 #define DAD_MFMA()                                                                               \
-    if constexpr (BDIR) { bh = breg[2 * u]; bl = breg[2 * u + 1]; }                              \
+    if constexpr (BDIR && X3) { bh = breg[2 * u]; bl = breg[2 * u + 1]; }                        \
+    if constexpr (BDIR && !X3) bh = breg[u];                                                     \
     if constexpr (X3) {                                                                          \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah),              \
                                                      __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);  \

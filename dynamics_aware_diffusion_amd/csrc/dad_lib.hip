@@ -469,18 +469,17 @@ template <> struct Tile<7> { static constexpr int BM = 64, BN = 64, SK = 2, KC =
 // 1x1 convs have one (tap, group) unit per 8 channels: a deep K chunk keeps enough MFMAs between
 // barriers (128 channels; 64 for the 128-row tile, whose stage would not fit LDS twice).
 // Split-f16 kernels consume 16 channels per unit: the chunk must give every split-K wave a unit.
-constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false) {
-    return (x3 && cfg_kc == 8)         ? 32          // wide tile, direct-B split-f16 kernel
+constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false, bool bd = false) {
+    return bd                          ? 32          // wide tile, direct-B kernel (either arithmetic)
            : (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128)
            : (x3 && cfg_kc < 16 * sk)  ? 16 * sk
                                        : cfg_kc;
 }
 
-template <int CFG, int TAPS, int STRIDE, bool X3>
+template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR = false>
 int launch_conv_t(ConvParams& p, hipStream_t st) {
     using T = Tile<CFG>;
-    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3);
-    constexpr bool BDIR = X3 && T::KC == 8;        // wide tile: weight fragments straight from global
+    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR);   // BDIR: weight fragments straight from global
     const int cin = p.cin0 + p.cin1;
     const bool ragged = (p.cin0 & 3) != 0 || (p.cin1 & 3) != 0 || p.cin0 % KC != 0 || cin % KC != 0;
     if (ragged && !(STRIDE == 1 && (TAPS == 5 || TAPS == 1)))
@@ -504,11 +503,10 @@ int launch_conv_t(ConvParams& p, hipStream_t st) {
 
 // Every kernel may use up to the full 160 KiB of LDS; raise the dynamic-LDS limit once
 // (not lazily, so that nothing but launches happens under hipGraph capture).
-template <int CFG, int TAPS, int STRIDE, bool X3>
+template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR = false>
 hipError_t raise_lds_limit() {
     using T = Tile<CFG>;
-    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3);
-    constexpr bool BDIR = X3 && T::KC == 8;
+    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR);
     hipError_t e = hipFuncSetAttribute(
         (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR>,
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -531,8 +529,9 @@ hipError_t raise_lds_limit_cfg() {
         if ((e = raise_lds_limit<CFG, 3, 2, true>()) != hipSuccess) return e;
         if ((e = raise_lds_limit<CFG, 2, 1, true>()) != hipSuccess) return e;
         if ((e = raise_lds_limit<CFG, 1, 1, true>()) != hipSuccess) return e;
-    } else {                                   // wide tile: the direct-B kernel of the GroupNorm'd 5-tap convs
-        if ((e = raise_lds_limit<CFG, 5, 1, true>()) != hipSuccess) return e;
+    } else {                                   // wide tile: the direct-B kernels of the GroupNorm'd 5-tap convs
+        if ((e = raise_lds_limit<CFG, 5, 1, true, true>()) != hipSuccess) return e;
+        if ((e = raise_lds_limit<CFG, 5, 1, false, true>()) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -558,7 +557,12 @@ int configure_kernels() {
 }
 
 template <int CFG>
-int launch_conv_cfg(ConvParams& p, int taps, int stride, bool x3, hipStream_t st) {
+int launch_conv_cfg(ConvParams& p, int taps, int stride, bool x3, bool bdir, hipStream_t st) {
+    if constexpr (Tile<CFG>::KC == 8) {
+        if (bdir && taps == 5 && stride == 1)
+            return x3 ? launch_conv_t<CFG, 5, 1, true, true>(p, st) : launch_conv_t<CFG, 5, 1, false, true>(p, st);
+    }
+    if (bdir) return fail(DAD_E_INVALID, "no direct-B kernel for tile %d taps=%d stride=%d", CFG, taps, stride);
     if constexpr (Tile<CFG>::KC >= 16) {
         if (x3) {
             if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, true>(p, st);
@@ -566,9 +570,6 @@ int launch_conv_cfg(ConvParams& p, int taps, int stride, bool x3, hipStream_t st
             if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1, true>(p, st);
             if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1, true>(p, st);
         }
-    }
-    if constexpr (Tile<CFG>::KC == 8) {
-        if (x3 && taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, true>(p, st);
     }
     if (x3) return fail(DAD_E_INVALID, "no split-f16 kernel for tile %d taps=%d stride=%d", CFG, taps, stride);
     if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, false>(p, st);
@@ -670,7 +671,7 @@ SplitPlan plan_split(const ConvOp& op, int cfg, int batch) {
     const TileCfg& t = kTiles[cfg];
     const int spt = t.BN / op.Lout;
     const long tiles = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
-    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3);
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
     const int nchunks = (op.cin0 + op.cin1 + kc - 1) / kc;      // chunks holding real channels
     SplitPlan sp{1, nchunks, 0};
     if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
@@ -730,7 +731,7 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.c1 = op.c1; p.c2 = op.c2;
     {
         const TileCfg& tc = kTiles[cfg];
-        const int kc = eff_kc(tc.KC, tc.BM, op.taps, tc.SK, op.x3);
+        const int kc = eff_kc(tc.KC, tc.BM, op.taps, tc.SK, op.x3, op.bdir);
         p.xswz = g_xswz_enabled ? find_xswz(op.Lout, op.stride, op.taps / 2, (kc + 4) / 4, tc.BN) : 0;
     }
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;     // tuning aid
@@ -743,14 +744,14 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
 #endif
     int rc;
     switch (cfg) {
-        case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, op.x3, st); break;
-        case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, op.x3, st); break;
-        case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, op.x3, st); break;
-        case 3: rc = launch_conv_cfg<3>(p, op.taps, op.stride, op.x3, st); break;
-        case 4: rc = launch_conv_cfg<4>(p, op.taps, op.stride, op.x3, st); break;
-        case 5: rc = launch_conv_cfg<5>(p, op.taps, op.stride, op.x3, st); break;
-        case 6: rc = launch_conv_cfg<6>(p, op.taps, op.stride, op.x3, st); break;
-        default: rc = launch_conv_cfg<7>(p, op.taps, op.stride, op.x3, st); break;
+        case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
+        case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
+        case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
+        case 3: rc = launch_conv_cfg<3>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
+        case 4: rc = launch_conv_cfg<4>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
+        case 5: rc = launch_conv_cfg<5>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
+        case 6: rc = launch_conv_cfg<6>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
+        default: rc = launch_conv_cfg<7>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
     }
     return rc;
 }
@@ -968,10 +969,10 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     for (ConvOp& op : m->plan.convs) {
         const HostTensor& w = m->raw[op.name + ".weight"];
         const HostTensor& b = m->raw[op.name + ".bias"];
-        // wide-group layers (op.kc == 8) in split-f16 mode use the direct-B kernel: 16-channel
-        // granules like every split image, whole 32-channel chunks, 5-tap stride-1 only
+        // wide-group layers (op.kc == 8) use the direct-B kernel in either arithmetic: 16-channel
+        // granules, whole 32-channel chunks, 5-tap stride-1 only (else the LDS-staged wide kernel)
         const int cin_all = op.cin0 + op.cin1;
-        op.bdir = m->precision == DAD_PREC_F16X3 && op.kc == 8 && op.kind == CONV_K5 &&
+        op.bdir = op.kc == 8 && op.kind == CONV_K5 &&
                   (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
         const int pack_g = op.bdir ? 16 : op.kc;
         std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad, pack_g)
@@ -980,7 +981,8 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
         // granules, and for the strided / transposed convs (no general staging path) whole
         // 64-channel chunks
         const int cin = op.cin0 + op.cin1;
-        op.x3 = op.bdir || (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
+        op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
+                (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
                             (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
                              ((op.cin0 & 63) == 0 && (cin & 63) == 0)));
         op.c1 = 1.0f; op.c2 = 0.0f;
