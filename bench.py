@@ -299,8 +299,7 @@ def main() -> None:
 
     # ---- the other conv arithmetic, same workload, same run (one GPU only; reported beside the
     # headline, never as `value`)
-    alt = None
-    if rank == 0 and world == 1 and args.inflight == 1 and not args.no_alt:
+    def run_alt():
         other = "f16x3" if args.precision == "fp32" else "fp32"
         pol2, diff2, cond2, _ = build_policy(arch, device, other, args.workload)
         diff2.use_graph = diff.use_graph
@@ -323,17 +322,26 @@ def main() -> None:
         diff.seed = diff2.seed = 4242
         pa = policy.sample_loop(batch_size=batch, conditions=cond, row_offset=0)
         pb = pol2.sample_loop(batch_size=batch, conditions=cond2, row_offset=0)
-        alt = {
+        return {
             "conv_arithmetic": other, "value": batch * args.steps / el2, "unit": "plans/s",
             "ms_per_step": el2 / args.steps * 1e3,
             "max_abs_diff_vs_headline_plans": float((pa - pb).abs().max()),
             "roofline": roofline_of(pol2, diff2, other, el2 / args.steps),
         }
-        del pol2, diff2
+
+    alt = None
+    if rank == 0 and world == 1 and args.inflight == 1 and not args.no_alt:
+        try:                                  # a failure here must not cost the headline line
+            alt = run_alt()
+        except Exception as exc:              # noqa: BLE001
+            alt = {"error": repr(exc)}
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(arch, batch, state, args.cpu_seconds, T)
+        try:
+            base = cpu_baseline(arch, batch, state, args.cpu_seconds, T)
+        except Exception as exc:              # noqa: BLE001
+            base = {"error": repr(exc)}
 
     if rank == 0:
         total_plans = world * batch * args.steps
