@@ -68,6 +68,9 @@ struct ConvOp {
     int kc = 16;             // K chunk the weights are packed for (8 when C_out/8 == 256)
     bool x3 = false;         // weights packed as split-f16 images (dad_model_set_precision)
     bool bdir = false;       // x3 on the wide tile: weight fragments go global -> registers
+    // identity residual over a channel concat (decoder block whose 2*C_in equals C_out): the two
+    // halves are copied side by side into the `res` buffer before this launch
+    int cat0 = -1, cat1 = -1, cat_c0 = 0, cat_c1 = 0;
     float c1 = 1.0f, c2 = 0.0f;   // x3: output scales 2^-s and 2^-(s+11)
     // device tensors (owned by the model)
     float* d_w = nullptr;
@@ -230,7 +233,6 @@ int build_plan(dad_model* m) {
     auto res_block = [&](const std::string& base, int in0, int in1, int cin0, int cin1, int cout,
                          int L) -> int {
         const int cin = cin0 + cin1;
-        if (cin == cout && in1 >= 0) return -100;   // identity residual of a concat: unsupported
         const int toff = temb_off;
         temb_off += cout;
         expect(m, base + ".time_mlp.1.weight", {cout, tdm});
@@ -239,13 +241,20 @@ int build_plan(dad_model* m) {
         conv(base + ".blocks.0.block.0", base + ".blocks.0.block.1", CONV_K5, in0, in1, cin0, cin1,
              cout, L, a0, -1, toff);
         int res = -1;
+        const bool cat_identity = cin == cout && in1 >= 0;   // nn.Identity over torch.cat([x, skip])
         if (cin != cout) {
             res = A.get((long)cout * L);
             conv(base + ".residual_conv", "", CONV_1X1, in0, in1, cin0, cin1, cout, L, res, -1, -1);
+        } else if (cat_identity) {
+            res = A.get((long)cout * L);
         }
         const int out = A.get((long)cout * L);
         conv(base + ".blocks.1.block.0", base + ".blocks.1.block.1", CONV_K5, a0, -1, cout, 0,
              cout, L, out, res >= 0 ? res : in0, -1);
+        if (cat_identity) {
+            ConvOp& last = P.convs.back();
+            last.cat0 = in0; last.cat1 = in1; last.cat_c0 = cin0; last.cat_c1 = cin1;
+        }
         A.put(a0);
         A.put(res);
         return out;
@@ -295,9 +304,6 @@ int build_plan(dad_model* m) {
         const int co = c.channels[lvl - 1];
         const std::string b = "ups." + std::to_string(j);
         const int u1 = res_block(b + ".0", x, skip, cx, cs, co, L);
-        if (u1 == -100)
-            return fail(DAD_E_INVALID, "decoder stage %d: identity residual over a channel concat "
-                        "(2*%d -> %d) is not supported", j, cx, co);
         A.put(x);
         A.put(skip);
         const int u2 = res_block(b + ".1", u1, -1, co, 0, co, L);
@@ -703,6 +709,13 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     auto buf = [&](int id) -> float* {
         return id >= 0 ? ws + m->plan.bufs[id].offset * (long)batch : nullptr;
     };
+    if (op.cat0 >= 0) {     // rows of [cat0 | cat1] side by side into the residual buffer
+        const long rows = (long)batch * op.Lout;
+        const long n4 = rows * ((op.cat_c0 + op.cat_c1) / 4);
+        hipLaunchKernelGGL(dad::concat_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                           buf(op.res), buf(op.cat0), buf(op.cat1), rows, op.cat_c0, op.cat_c1);
+        HIP_TRY(hipGetLastError());
+    }
     ConvParams p{};
     p.src0 = op.src0 == -2 ? xext : buf(op.src0);
     p.src1 = buf(op.src1);

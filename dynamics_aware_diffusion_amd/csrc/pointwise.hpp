@@ -54,6 +54,20 @@ __global__ void fill_normal_kernel(float* x, long n_elems, uint64_t elem_offset,
     if (i < n_elems) x[i] = philox_normal(elem_offset + (uint64_t)i, draw, seed);
 }
 
+// dst[r][0:c0] = a[r][:], dst[r][c0:c0+c1] = b[r][:]  (float4 granularity; c0, c1 multiples of 4).
+// torch.cat([x, skip], dim=1) made real — only for the identity residual of a decoder block whose
+// input concat is as wide as its output; every other concat stays virtual (two source pointers).
+__global__ void concat_rows_kernel(float* dst, const float* a, const float* b, long rows, int c0, int c1) {
+    const int q = (c0 + c1) >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * q) return;
+    const long r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    const float4 v = c < c0 ? *reinterpret_cast<const float4*>(a + r * c0 + c)
+                            : *reinterpret_cast<const float4*>(b + r * c1 + (c - c0));
+    *reinterpret_cast<float4*>(dst + r * (c0 + c1) + c) = v;
+}
+
 // -------------------------------------------------------------- final conv + posterior
 struct FinalParams {
     const float* act;        // [B*H][dim] channels-last output of final_conv[0]

@@ -314,6 +314,9 @@ def test_graph_replay_with_inkernel_noise(dev):
     (23, 64, (1, 1, 2), 64, 2),        # horizon 64: one sample per 64-row tile; repeated width
     (3, 32, (1,), 32, 4),              # single level: no down/up-sampling, no skip is popped
     (8, 128, (1, 4), 8, 9),            # horizon 8 -> L = 8, 4; wide jump 128 -> 512
+    (6, 32, (1, 4, 2), 32, 3),         # shrinking widths: decoder block with an IDENTITY residual
+                                       # over the channel concat (2*64 == 128)
+    (5, 32, (1, 4, 2, 1), 32, 2),      # two such stages
 ], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}")
 def test_assorted_architectures_match_oracle(arch, dev):
     """Shapes outside the three BASELINE architectures, against the oracle on seeded inputs."""
