@@ -103,7 +103,14 @@ struct ConvParams {
     int32_t lshift;      // log2(Lout)
     int32_t lshift_in;   // log2(Lin)
     int32_t interleave;  // transposed-conv store: col m<M/2 -> row 2l, m>=M/2 -> row 2l+1
-    int32_t ntiles_n;    // number of N tiles (for the XCD-aware tile order)
+    int32_t ntiles_n;    // number of N tiles
+    // XCD-aware tile order (xcd_gn > 0): the launch is (K slices, MT*NT tiles) and the hardware deals
+    // consecutive workgroups to the 8 XCDs round-robin.  The XCDs form a gm x gn grid (gm*gn = 8);
+    // XCD (i, j) owns M tiles [i*MT/gm, ..) x N tiles [j*NT/gn, ..), so a weight slab is fetched by gn
+    // XCDs and an activation slab by gm of them instead of 1 and 8 (or 8 and 1).
+    int32_t xcd_gn;      // 0: plain 3-D grid (y = M tile, z = N tile)
+    int32_t xcd_mts;     // log2(MT / gm): M tiles per XCD
+    int32_t xcd_ntn;     // NT / gn: N tiles per XCD
     // grid-level split-K (few tiles: small batches, the deepest levels of wide nets)
     int32_t kslices;     // blocks per output tile (1 = off)
     int32_t chunks_per_slice;
@@ -243,13 +250,19 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int l32 = lane & 31;
     const int h = lane >> 5;
 
-    // Grid = (K slices, M tiles, N tiles): no index arithmetic on the critical path to the first
-    // global load.  Hardware deals linear block ids (x fastest) round-robin over the 8 XCDs, so
-    // with this order the blocks that share a weight slab (same M tile) mostly share an XCD's
-    // L2, and the K slices of one tile are neighbours (speed only; any placement is correct).
+    // Grid = (K slices, M tiles, N tiles), or (K slices, tiles) with the XCD-aware order below.
+    // Hardware deals linear block ids (x fastest) round-robin over the 8 XCDs; which tiles meet
+    // in one XCD's L2 decides how often the weight and activation slabs are fetched from memory
+    // (speed / traffic only; any placement is correct).
     const int kb = blockIdx.x;                   // this block's K slice of its output tile
-    const int mt = blockIdx.y;
-    const int nt = blockIdx.z;
+    int mt = blockIdx.y;
+    int nt = blockIdx.z;
+    if (p.xcd_gn > 0) {                          // scalar arithmetic only (blockIdx is uniform)
+        const int wg = blockIdx.y, c = wg & 7, j = wg >> 3;
+        const int im = c / p.xcd_gn, in = c - im * p.xcd_gn;
+        mt = (im << p.xcd_mts) + (j & ((1 << p.xcd_mts) - 1));
+        nt = in * p.xcd_ntn + (j >> p.xcd_mts);
+    }
     const int tile = mt * p.ntiles_n + nt;       // id for the split-K slab / ticket
 
     const int Lin = p.Lin, Lout = p.Lout;

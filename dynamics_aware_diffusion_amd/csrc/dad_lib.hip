@@ -25,6 +25,7 @@ thread_local char g_err[1024] = "";
 int g_force_tile = -1;      // dad_debug_set_tile: tuning / test hook
 bool g_split_enabled = true;
 bool g_xswz_enabled = getenv("DAD_NO_XSWZ") == nullptr;     // A/B switch for the LDS row shifts
+bool g_xcd_order = getenv("DAD_NO_XCD_ORDER") == nullptr;    // A/B switch for the XCD-aware tile order
 #ifdef DAD_STAMPS
 unsigned long long* g_stamps = nullptr;
 #endif
@@ -501,7 +502,27 @@ int launch_conv_t(ConvParams& p, hipStream_t st) {
     const int spt = T::BN / p.Lout;
     p.ntiles_n = (p.B + spt - 1) / spt;
     if (p.ntiles_n > 65535) return fail(DAD_E_INVALID, "batch too large for one launch (%d N tiles)", p.ntiles_n);
-    hipLaunchKernelGGL(kern, dim3(p.kslices, p.M / T::BM, p.ntiles_n),
+    // XCD-aware tile order when every XCD gets the same whole rectangle of tiles: choose the
+    // gm x gn arrangement of the 8 XCDs that minimises  gn * (weight bytes) + gm * (activation bytes)
+    const int MT = p.M / T::BM, NTn = p.ntiles_n;
+    dim3 grid(p.kslices, MT, NTn);
+    p.xcd_gn = 0;
+    if (g_xcd_order && p.kslices == 1 && (MT & (MT - 1)) == 0 && (long)MT * NTn <= 65535 && ((long)MT * NTn) % 8 == 0) {
+        const double wbytes = (double)p.M * TAPS * (p.cin0 + p.cin1);
+        const double xbytes = (double)p.B * p.Lin * (p.cin0 + p.cin1);
+        double best = -1;
+        for (int gm = 1; gm <= 8; gm *= 2) {
+            const int gn = 8 / gm;
+            if (MT % gm != 0 || NTn % gn != 0) continue;
+            const double cost = gn * wbytes + gm * xbytes;
+            if (best < 0 || cost < best) {
+                best = cost;
+                p.xcd_gn = gn; p.xcd_mts = ilog2(MT / gm); p.xcd_ntn = NTn / gn;
+            }
+        }
+        if (p.xcd_gn > 0) grid = dim3(p.kslices, MT * NTn, 1);
+    }
+    hipLaunchKernelGGL(kern, grid,
                        dim3(64 * (T::BM / 32) * (T::BN / 32) * T::SK), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;
