@@ -5,8 +5,9 @@
 draws random supported architectures (dim, dim_mults incl. shrinking widths, horizon,
 transition_dim), batch sizes and conv arithmetics, runs one denoiser evaluation through the HIP
 path and compares it with the CPU oracle at the forward tolerance of the parity tests (5e-6).
-Round 1: seeds 1, 7, 11, 12, 13 x 40 cases, 0 failures, 0 refusals (the first sweep found the
-identity-residual-over-concat decoder block, since supported)."""
+and a short conditioned sampling loop with injected noise (2e-5).
+Round 1: seeds 1, 7, 11, 12, 13 (forward) and 21, 22 (forward + loop) x 40 cases, 0 failures,
+0 refusals (the first sweep found the identity-residual-over-concat decoder block, since supported)."""
 import sys, random
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,9 +39,21 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
             want = orc.unet_forward(w, x, torch.full((B,), t, dtype=torch.long))
         got = diff.model(x.to(dev), t); torch.cuda.synchronize()
         err = float((got.cpu() - want).abs().max())
-        flag = "" if err <= 5e-6 else "   <<<<<< FAIL"
+        # and a short conditioned sampling loop with injected noise (<= 2e-5, the loop tolerance)
+        T = rng.randint(3, 12)
+        Bl = min(B, 8)
+        noise = torch.from_numpy(synth.normal_like(300 + it, "fuzz.noise", (T + 1, Bl, H, td)))
+        cond = torch.from_numpy(synth.uniform(300 + it, "fuzz.cond", (1, td), 0.9))
+        want_loop = orc.sample_loop(w, orc.schedule_buffers("cosine", 20), noise, T, {0: cond})
+        eng = diff._engine(dev)
+        xl = noise[0].to(dev).clone()
+        xl[:, 0] = cond.to(dev)
+        eng.sample_loop(xl, T, noise_stack=noise[1:].to(dev).contiguous(), cond0=cond.to(dev))
+        torch.cuda.synchronize()
+        errl = float((xl.cpu() - want_loop).abs().max())
+        flag = "" if err <= 5e-6 and errl <= 2e-5 else "   <<<<<< FAIL"
         if flag: bad += 1
-        print(f"{it:3d} dim={dim} mults={mults} H={H} td={td} B={B} {prec} t={t}: {err:.2e}{flag}", flush=True)
+        print(f"{it:3d} dim={dim} mults={mults} H={H} td={td} B={B} {prec} t={t}: fwd {err:.2e} loop(T={T}) {errl:.2e}{flag}", flush=True)
         del unet, diff
     except Exception as e:
         msg = str(e)[:110]
