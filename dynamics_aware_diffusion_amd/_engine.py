@@ -7,6 +7,7 @@ device the calls raise.  torch is used only for device memory and streams.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import Dict, Mapping, Optional, Sequence
 
@@ -54,6 +55,7 @@ ABI = {
     "dad_model_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p,
                                         C.POINTER(C.c_int64), C.c_int32]),
     "dad_model_load_schedule": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    "dad_model_load_time_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "dad_model_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_model_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t)]),
@@ -70,7 +72,11 @@ ABI = {
                               C.c_int32, C.c_void_p]),
     "dad_fill_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64,
                                   C.c_uint64, C.c_void_p]),
-    "dad_debug_set_tile": (C.c_int, [C.c_int32]),
+    "dad_debug_set_tile": (C.c_int, [C.c_void_p, C.c_int32]),
+    "dad_debug_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "dad_debug_read_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.POINTER(C.c_int32)]),
+    "dad_debug_mish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dad_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_double)]),
@@ -124,6 +130,18 @@ def _require_device(t: torch.Tensor, name: str) -> None:
 
 
 PRECISIONS = {"fp32": 0, "f16x3": 1}      # DAD_PREC_* of include/dad.h
+TABLES = {"sinusoid": 0, "time_mlp": 1, "blocks": 2}      # DAD_TABLE_* of include/dad.h
+
+
+def sinusoid_table(n_timesteps: int, dim: int) -> torch.Tensor:
+    """SinusoidalPosEmb for t = 0 .. n_timesteps-1 with the reference's own torch expression
+    (/root/reference/m_diffuser/models/temporal_unet.py:27-31), on the host: (n_timesteps, dim)
+    fp32, bit-identical to what the reference's module computes on this machine."""
+    half = dim // 2
+    scale = math.log(10000) / (half - 1)
+    freqs = torch.exp(torch.arange(half) * -scale)
+    arg = torch.arange(n_timesteps)[:, None] * freqs[None, :]
+    return torch.cat((arg.sin(), arg.cos()), dim=-1).contiguous()
 
 SCHEDULE_KEYS = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
                  "posterior_mean_coef1", "posterior_mean_coef2",
@@ -197,6 +215,9 @@ class HipEngine:
                                  f"{self.n_timesteps}")
             bufs.append(b)
         _check(self.lib, self.lib.dad_model_load_schedule(self._h, *[b.data_ptr() for b in bufs]))
+        emb = sinusoid_table(self.n_timesteps, int(self.cfg.dim))
+        _check(self.lib, self.lib.dad_model_load_time_embedding(
+            self._h, emb.data_ptr(), self.n_timesteps, int(self.cfg.dim)))
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.dad_model_finalize(self._h, self._stream()))
         self.ready = True
@@ -309,6 +330,32 @@ class HipEngine:
             _check(self.lib, self.lib.dad_fill_normal(
                 x.data_ptr(), B, x.numel() // B, int(seed), int(row_offset), int(draw),
                 self._stream()))
+
+    # ------------------------------------------------------------------ test / tuning hooks
+    def debug_set_tile(self, cfg: int) -> None:
+        """Force a conv tile (0..7), -1 = heuristic, 100+cfg / 99 = same without grid split-K."""
+        _check(self.lib, self.lib.dad_debug_set_tile(self._h, int(cfg)))
+
+    def debug_set_option(self, name: str, value: int) -> None:
+        _check(self.lib, self.lib.dad_debug_set_option(self._h, name.encode(), int(value)))
+
+    def read_table(self, which: str, t: int) -> torch.Tensor:
+        """Row t of a per-timestep table (see DAD_TABLE_* in include/dad.h), as a CPU tensor."""
+        out = torch.empty(1 << 16, dtype=torch.float32)
+        width = C.c_int32()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_debug_read_table(self._h, TABLES[which], int(t),
+                                                           out.data_ptr(), out.numel(), C.byref(width)))
+        return out[:width.value].clone()
+
+    def mish(self, x: torch.Tensor) -> torch.Tensor:
+        """The conv epilogue's Mish applied to a device tensor (test hook)."""
+        _require_device(x, "x")
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_debug_mish(x.data_ptr(), out.data_ptr(), x.numel(),
+                                                     self._stream()))
+        return out
 
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on: bool) -> None:

@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "conv_shapes.hpp"
+
 namespace dad {
 
 #define DAD_LBID (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
@@ -117,6 +119,11 @@ struct ConvParams {
     float c1, c2;        // split-f16 kernels: out = acc_hh * c1 + acc_cross * c2  (2^-s, 2^-s-11)
     uint64_t xswz;       // 16 x 4 bits: sample s of the tile sits xswz[s] 16-byte slots further right
                          // in the X stage (bank-conflict-free ds_read_b128 at L <= 16; 0 = plain)
+    // RES kernels: the block's 1x1 residual conv (temporal_unet.py:117-121) rides along as tap
+    // index TAPS of the weight image — same staged rows (centre tap), own accumulators, bias only.
+    int32_t wtaps;       // tap slots per (chunk, granule) of the weight image (TAPS, or TAPS + 1)
+    const float* rbias;  // [M] residual-conv bias
+    float* rdst;         // [B*Lout][M] residual-conv output
     float* slab;         // [tiles][kslices][BN*BM] fp32 partial tiles (workspace)
     unsigned* counters;  // [tiles] arrival tickets, zero between launches
 #ifdef DAD_STAMPS
@@ -185,22 +192,6 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
 // host so that every group sees 16 distinct slots (ConvParams::xswz; dad_lib.hip find_xswz).  A
 // shift moves a sample's trailing halo over the next sample's leading halo — zeros over zeros;
 // the search keeps it off the neighbour's real rows.  The stage grows by 15 slots.
-constexpr int kXSwzPad = 64;    // floats
-// Rows of the X stage: every sample of the tile with its zero halo.
-__host__ __device__ inline int conv_xrows(int BN, int Lin, int Lout, int taps) {
-    return (BN / Lout) * (Lin + 2 * (taps / 2));
-}
-// LDS floats of one block (the host sizes the dynamic allocation with the same formula).
-__host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int taps, int Lin,
-                                                  int Lout, int SK, bool bdir = false) {
-    const size_t kp = KC + 4;
-    const size_t stage = (size_t)conv_xrows(BN, Lin, Lout, taps) * kp + kXSwzPad +
-                         (bdir ? 0 : (size_t)taps * BM * kp);
-    const size_t epi = (size_t)SK * BN * (BM + 4) + 64;
-    const size_t k = 2 * stage;
-    return k > epi ? k : epi;
-}
-
 // BDIR: the B operand (weights) goes global -> registers directly, no LDS.  For
 // tiles one wave-tile wide (BN = 32) every weight fragment is used by exactly one wave, so staging
 // it through LDS buys no sharing and only costs capacity: the 256-row tile of the 2048-channel
@@ -209,13 +200,15 @@ __host__ __device__ inline size_t conv_lds_floats(int BM, int BN, int KC, int ta
 // roll like the staged items: those of unit u are consumed by the unit's MFMAs and the registers
 // immediately receive the same unit of the next chunk.  Weights are packed in 16-channel granules
 // for both arithmetics: [granule][tap][M][16 floats] (split-f16: 16 hi halves | 16 lo halves).
-template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED, bool X3 = false, bool BDIR = false>
+template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED, bool X3 = false, bool BDIR = false,
+          bool RES = false>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32(const ConvParams p) {
     constexpr int TMW = BM / 32;                 // wave tiles along M
     constexpr int TNW = BN / 32;                 // wave tiles along N
     constexpr int WT = TMW * TNW;
     constexpr int NT = 64 * WT * SK;
     constexpr int PAD = TAPS / 2;
+    constexpr int WTAPS = TAPS + (RES ? 1 : 0);  // weight taps staged per chunk (RES: + the 1x1 ride)
     constexpr int KP = KC + 4;                   // LDS row stride (floats): 16-B aligned, odd in
                                                  // 16-B units -> conflict-free ds_read_b128
     constexpr int KU = X3 ? 16 : 8;              // channels per unit: 4 fp32 MFMAs (k=2 each) or
@@ -227,6 +220,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     constexpr int NSUB = KC / KG;                // packed granules per chunk
     static_assert(KC % KU == 0 && G % SK == 0 && GW >= 1, "K chunk must split evenly over the SK waves");
     static_assert(!BDIR || (BN == 32 && SK == 1 && !RAGGED && KC >= 16), "direct-B tiles");
+    static_assert(!RES || (!X3 && !BDIR && TAPS == 5 && STRIDE == 1), "the residual ride exists for fp32 5-tap convs");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Vector accesses go through these views with an index in vector units: every offset below
@@ -275,7 +269,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const int nvalid = min(SPT, p.B - s0);
 
     const int XF = XROWS * KP + kXSwzPad;
-    const int STAGE = XF + (BDIR ? 0 : TAPS * BM * KP);   // floats per stage: [X rows][W rows]
+    const int STAGE = XF + (BDIR ? 0 : WTAPS * BM * KP);  // floats per stage: [X rows][W rows]
     const int STAGE4 = STAGE >> 2;               // the same in float4 units (every term is a multiple of 4)
 
 
@@ -293,8 +287,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     // the epilogue: 4x shorter fp32 chains than a single accumulator (K reaches 20480 on the wide
     // nets), at no cost in matrix-pipe time
     f32x16 acc, acc2, acc3, acc4;
+    f32x16 accr, accr2;                          // RES: the riding 1x1 conv (two chains)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; acc3[r] = 0.0f; acc4[r] = 0.0f; }
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; acc3[r] = 0.0f; acc4[r] = 0.0f; accr[r] = 0.0f; accr2[r] = 0.0f; }
 
     const int cin = p.cin0 + p.cin1;
     const int c_begin = kb * p.chunks_per_slice;
@@ -306,7 +301,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #endif
 
     // ---- staging: global -> registers (prefetch) -> LDS ---------------------------------
-    constexpr int W_F4 = TAPS * BM * KC / 4;
+    constexpr int W_F4 = WTAPS * BM * KC / 4;
     constexpr int W_PER_T = BDIR ? 0 : (W_F4 + NT - 1) / NT;   // staged W items (none in direct-B mode)
     constexpr int W_ARR = W_PER_T ? W_PER_T : 1;
     constexpr int KQ = KC / 4;                              // float4 per row
@@ -327,7 +322,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int tap = row / BM;
         const int mm = row - tap * BM;
         const int sub = q / GQ;
-        w_goff[i] = ((sub * TAPS + tap) * M + m0 + mm) * KG + (q - sub * GQ) * 4;
+        w_goff[i] = ((sub * p.wtaps + tap) * M + m0 + mm) * KG + (q - sub * GQ) * 4;
         w_loff[i] = (XF + row * KP + q * 4) >> 2;         // float4 units
     }
 #pragma unroll
@@ -348,7 +343,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         x_loff[i] = e < xrows_real * KQ ? (X3 ? xo >> 1 : xo >> 2) : -1;
     }
     DAD_PSTAMP(6);
-    const long w_chunk_stride = (long)NSUB * TAPS * M * KG;
+    const long w_chunk_stride = (long)NSUB * p.wtaps * M * KG;
     // RAGGED = false promises (host-checked) that every K chunk lies inside one concat source and
     // below cin, with 16-byte aligned channel quads: the X loads use one base pointer per chunk.
     // RAGGED = true is the general path: first layer (cin = transition_dim), narrow nets.
@@ -430,12 +425,13 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     // Fragments are read one unit ahead of the MFMAs that consume them; the chunk's single barrier
     // sits in FRONT of its last unit's MFMAs: the first fragments of the next chunk are fetched
     // behind the barrier while those MFMAs run, so the matrix pipe does not drain at the barrier.
-    constexpr int UW = TAPS * GW;                       // units per wave per chunk
+    constexpr int UW = WTAPS * GW;                      // units per wave per chunk
     const int koff = ks * (GW * KU);                    // this wave's units in a chunk
     const int afrag4 = (arow + koff) >> 2;              // float4 units: the constant parts of the
     const int bfrag4 = (brow + koff) >> 2;              // fragment addresses fold into ds_read offsets
     auto frag_a = [&](int stage, int u, int lo) -> float4 {   // lo = 8: the residual halves (X3)
-        const int tap = u / GW, gw = u - tap * GW;
+        const int wtap = u / GW, gw = u - wtap * GW;
+        const int tap = (RES && wtap == TAPS) ? PAD : wtap;   // the 1x1 ride reads the centre rows
         return smem4[stage * STAGE4 + afrag4 + tap * (KP / 4) + gw * (KU / 4) + lo / 4];
     };
     auto frag_b = [&](int stage, int u, int lo) -> float4 {
@@ -450,12 +446,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     auto bload = [&](int u, int chunk) {
         const int tap = u / GW, gw = u - tap * GW;
         if constexpr (X3) {                             // unit = one 16-channel granule: hi, lo
-            const float* q = bsrc + (long)chunk * w_chunk_stride + (long)((gw * TAPS + tap) * M) * 16;
+            const float* q = bsrc + (long)chunk * w_chunk_stride + (long)((gw * p.wtaps + tap) * M) * 16;
             breg[2 * u] = ldg4(q);
             breg[2 * u + 1] = ldg4(q + 8);
         } else {                                        // unit = 8 channels = half a granule
             const float* q = bsrc + (long)chunk * w_chunk_stride +
-                             (long)(((gw >> 1) * TAPS + tap) * M) * 16 + (gw & 1) * 8;
+                             (long)(((gw >> 1) * p.wtaps + tap) * M) * 16 + (gw & 1) * 8;
             breg[u] = ldg4(q);
         }
     };
@@ -611,6 +607,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
                                                       __builtin_bit_cast(f16x8, bl), acc2, 0, 0, 0); \
         acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al),             \
                                                       __builtin_bit_cast(f16x8, bh), acc3, 0, 0, 0); \
+    } else if (RES && u / GW == TAPS) {                                                          \
+        accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.x, bh.x, accr, 0, 0, 0);                  \
+        accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.y, bh.y, accr2, 0, 0, 0);                \
+        accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.z, bh.z, accr, 0, 0, 0);                  \
+        accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.w, bh.w, accr2, 0, 0, 0);                \
     } else {                                                                                     \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.x, bh.x, acc, 0, 0, 0);                    \
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah.y, bh.y, acc2, 0, 0, 0);                  \
@@ -693,6 +694,34 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         y[k][0] = v.x; y[k][1] = v.y; y[k][2] = v.z; y[k][3] = v.w;
+    }
+
+    if constexpr (RES) {
+        // The riding 1x1 conv: same exchange through E, same ownership (any bijection of tile
+        // elements onto threads will do without GroupNorm), bias, store.  Its stores fly while
+        // the GroupNorm reductions below run.
+        __syncthreads();                               // every thread has read its main-tile values
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int col = tm * 32 + l32;
+            E[ks * ECOPY + row * ES + col] = accr[r] + accr2[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < F4PL; ++k) {
+            const float* q = E + erow[k] * ES + ecol[k];
+            float4 v = *reinterpret_cast<const float4*>(q);
+#pragma unroll
+            for (int c = 1; c < SK; ++c) {
+                const float4 u = *reinterpret_cast<const float4*>(q + c * ECOPY);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const float4 rb = ldg4(p.rbias + m0 + ecol[k]);
+            if (eoff[k] >= 0)
+                *reinterpret_cast<float4*>(p.rdst + eoff[k]) =
+                    make_float4(v.x + rb.x, v.y + rb.y, v.z + rb.z, v.w + rb.w);
+        }
     }
 
     if (p.kslices > 1) {

@@ -11,32 +11,25 @@
 #include <functional>
 #include <map>
 #include <memory>
-#include <mutex>
 #include <string>
 #include <vector>
 
+#include <mutex>
+#include <set>
+#include <tuple>
+
 #include "../../include/dad.h"
+#include "host_plan.hpp"
 #include "conv_gemm.hpp"
 #include "pointwise.hpp"
 
+using namespace dadhost;
+
 namespace {
 
-thread_local char g_err[1024] = "";
-int g_force_tile = -1;      // dad_debug_set_tile: tuning / test hook
-bool g_split_enabled = true;
-bool g_xswz_enabled = getenv("DAD_NO_XSWZ") == nullptr;     // A/B switch for the LDS row shifts
-bool g_xcd_order = getenv("DAD_NO_XCD_ORDER") == nullptr;    // A/B switch for the XCD-aware tile order
 #ifdef DAD_STAMPS
 unsigned long long* g_stamps = nullptr;
 #endif
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
 
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
@@ -46,73 +39,12 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                            \
     } while (0)
 
-struct HostTensor {
-    std::vector<float> data;
-    std::vector<int64_t> shape;
-};
-
-enum ConvKind { CONV_K5 = 0, CONV_1X1 = 1, CONV_DOWN = 2, CONV_UP = 3 };
-
-// One conv-GEMM launch of the plan.  Buffer ids index Plan::bufs; -1 = none,
-// -2 = the external (B,H,td) trajectory tensor.
-struct ConvOp {
-    std::string name;        // weight key prefix, e.g. "downs.0.0.blocks.0.block.0"
-    std::string norm;        // GroupNorm key prefix or ""
-    ConvKind kind;
-    int taps, stride;
-    int cin0, cin1, cin_pad;
-    int cout;                // real output channels
-    int M;                   // GEMM rows (2*cout for CONV_UP)
-    int Lin, Lout;           // GEMM per-sample lengths (CONV_UP: Lout == Lin, stores 2*Lin)
-    int src0, src1, dst, res;
-    int temb_off;            // offset into the per-t table, or -1
-    int kc = 16;             // K chunk the weights are packed for (8 when C_out/8 == 256)
-    bool x3 = false;         // weights packed as split-f16 images (dad_model_set_precision)
-    bool bdir = false;       // x3 on the wide tile: weight fragments go global -> registers
-    // identity residual over a channel concat (decoder block whose 2*C_in equals C_out): the two
-    // halves are copied side by side into the `res` buffer before this launch
-    int cat0 = -1, cat1 = -1, cat_c0 = 0, cat_c1 = 0;
-    float c1 = 1.0f, c2 = 0.0f;   // x3: output scales 2^-s and 2^-(s+11)
-    // device tensors (owned by the model)
-    float* d_w = nullptr;
-    float* d_bias = nullptr;
-    float* d_gamma = nullptr;
-    float* d_beta = nullptr;
-    double flops_per_sample = 0;
-};
-
-struct Buf {
-    long per_sample;   // floats per batch row
-    long offset;       // floats per batch row, from workspace start
-};
-
-struct Plan {
-    std::vector<ConvOp> convs;
-    std::vector<Buf> bufs;
-    long floats_per_sample = 0;
-    int final_act = -1;       // buffer holding final_conv[0] output
-    int temb_width = 0;       // sum of C_out over residual blocks
-};
-
-constexpr int kMaxSplitTiles = 4096;
-struct TileCfg { int BM, BN, SK, KC; };
-// Block tile (BM channels x BN positions), SK-way intra-block split-K, K chunk.  Every
-// configuration runs 8 waves per block except the last (4 waves, two blocks per CU).
-const TileCfg kTiles[] = {
-    {32, 64, 4, 32},    // 0: few output tiles -> deepest split-K
-    {64, 64, 2, 32},    // 1: the workhorse at batch 256
-    {128, 64, 1, 16},   // 2: GroupNorm groups of 128 channels / plentiful tiles
-    {256, 32, 1, 8},    // 3: GroupNorm groups of 256 channels (C = 2048)
-    {64, 64, 1, 16},    // 4: plentiful tiles, 4 waves
-    {32, 64, 2, 16},    // 5: 4 waves, small LDS: several independent blocks per CU
-    {32, 64, 1, 16},    // 6: 2 waves
-    {64, 64, 2, 16},    // 7: as 1 with the shallower K chunk (two blocks per CU fit)
-};
-
-
+// Everything a captured loop freezes: pointers, sizes and the scalars baked into its launches.
 struct GraphKey {
-    const void* x; const void* noise; const void* cond; const void* ws; const void* P;
-    int n_steps, batch, cond_per_row, pad_ = 0;
+    const void* x; const void* noise; const void* cond; const void* ws;
+    const void* P; const void* obs_mean; const void* obs_std; const void* act_mean; const void* act_std;
+    int n_steps, batch, cond_per_row, state_dim, observation_dim, action_dim;
+    int force_tile, flags;    // tile / split-K / fusion hooks change the captured launches
     uint64_t row_offset;
     uint64_t alpha_hash;      // projection strengths are baked into the captured launches
     bool operator<(const GraphKey& o) const {
@@ -122,17 +54,16 @@ struct GraphKey {
 
 }  // namespace
 
-struct dad_model {
-    dad_cfg cfg;
-    std::map<std::string, HostTensor> raw;
-    std::map<std::string, std::vector<int64_t>> expected;     // key -> shape
-    Plan plan;
+struct dad_model : HostModel {
     bool finalized = false;
-    int precision = DAD_PREC_FP32;                             // dad_model_set_precision
+    int device = -1;                                           // device the parameters live on
     std::vector<float> sched[5];                               // host schedule scalars
     bool have_sched = false;
+    std::vector<float> emb_override;                           // dad_model_load_time_embedding
     // device
-    float* d_temb_table = nullptr;    // [T][temb_width]
+    float* d_emb = nullptr;           // [T][dim]      SinusoidalPosEmb
+    float* d_temb = nullptr;          // [T][time_dim] time_mlp output
+    float* d_temb_table = nullptr;    // [T][temb_width] every block's Mish -> Linear
     float* d_final_w = nullptr;       // [td][dim]
     float* d_final_b = nullptr;
     uint64_t* d_rng = nullptr;
@@ -158,257 +89,6 @@ namespace {
 
 using dad::ConvParams;
 
-int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
-bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-
-// ----------------------------------------------------------------------------- planning
-struct Allocator {
-    std::vector<Buf>& bufs;
-    std::vector<bool> in_use;
-    explicit Allocator(std::vector<Buf>& b) : bufs(b) {}
-    int get(long per_sample) {
-        int best = -1;
-        for (size_t i = 0; i < bufs.size(); ++i)
-            if (!in_use[i] && bufs[i].per_sample >= per_sample &&
-                (best < 0 || bufs[i].per_sample < bufs[best].per_sample))
-                best = (int)i;
-        if (best < 0) {
-            bufs.push_back({per_sample, 0});
-            in_use.push_back(false);
-            best = (int)bufs.size() - 1;
-        }
-        in_use[best] = true;
-        return best;
-    }
-    void put(int id) { if (id >= 0) in_use[id] = false; }
-};
-
-void expect(dad_model* m, const std::string& key, std::vector<int64_t> shape) {
-    m->expected[key] = std::move(shape);
-}
-
-// Emits the launch plan of TemporalUnet.forward (temporal_unet.py:199-241) including the
-// reference's always-upsample decoder and unused level-0 skip.
-int build_plan(dad_model* m) {
-    const dad_cfg& c = m->cfg;
-    Plan& P = m->plan;
-    Allocator A(P.bufs);
-    const int k = c.kernel_size;
-    const int tdm = c.time_dim;
-    int temb_off = 0;
-
-    auto conv = [&](const std::string& name, const std::string& norm, ConvKind kind, int src0,
-                    int src1, int cin0, int cin1, int cout, int Lin, int dst, int res,
-                    int toff) {
-        ConvOp op;
-        op.name = name; op.norm = norm; op.kind = kind;
-        op.cin0 = cin0; op.cin1 = cin1;
-        op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
-        const int padto = op.kc == 8 ? 8 : (kind == CONV_1X1 ? 128 : 64);   // deepest K chunk of its kernels
-        op.cin_pad = (cin0 + cin1 + padto - 1) / padto * padto;
-        op.cout = cout; op.src0 = src0; op.src1 = src1; op.dst = dst; op.res = res;
-        op.temb_off = toff; op.Lin = Lin;
-        const int cin = cin0 + cin1;
-        switch (kind) {
-            case CONV_K5: op.taps = k; op.stride = 1; op.M = cout; op.Lout = Lin;
-                expect(m, name + ".weight", {cout, cin, k});
-                op.flops_per_sample = 2.0 * cout * cin * k * Lin; break;
-            case CONV_1X1: op.taps = 1; op.stride = 1; op.M = cout; op.Lout = Lin;
-                expect(m, name + ".weight", {cout, cin, 1});
-                op.flops_per_sample = 2.0 * cout * cin * Lin; break;
-            case CONV_DOWN: op.taps = 3; op.stride = 2; op.M = cout; op.Lout = Lin / 2;
-                expect(m, name + ".weight", {cout, cin, 3});
-                op.flops_per_sample = 2.0 * cout * cin * 3 * (Lin / 2); break;
-            case CONV_UP: op.taps = 2; op.stride = 1; op.M = 2 * cout; op.Lout = Lin;
-                expect(m, name + ".weight", {cin, cout, 4});
-                op.flops_per_sample = 2.0 * cout * cin * 4 * Lin; break;   // algorithmic
-        }
-        expect(m, name + ".bias", {cout});
-        if (!norm.empty()) {
-            expect(m, norm + ".weight", {cout});
-            expect(m, norm + ".bias", {cout});
-        }
-        P.convs.push_back(op);
-    };
-
-    auto res_block = [&](const std::string& base, int in0, int in1, int cin0, int cin1, int cout,
-                         int L) -> int {
-        const int cin = cin0 + cin1;
-        const int toff = temb_off;
-        temb_off += cout;
-        expect(m, base + ".time_mlp.1.weight", {cout, tdm});
-        expect(m, base + ".time_mlp.1.bias", {cout});
-        const int a0 = A.get((long)cout * L);
-        conv(base + ".blocks.0.block.0", base + ".blocks.0.block.1", CONV_K5, in0, in1, cin0, cin1,
-             cout, L, a0, -1, toff);
-        int res = -1;
-        const bool cat_identity = cin == cout && in1 >= 0;   // nn.Identity over torch.cat([x, skip])
-        if (cin != cout) {
-            res = A.get((long)cout * L);
-            conv(base + ".residual_conv", "", CONV_1X1, in0, in1, cin0, cin1, cout, L, res, -1, -1);
-        } else if (cat_identity) {
-            res = A.get((long)cout * L);
-        }
-        const int out = A.get((long)cout * L);
-        conv(base + ".blocks.1.block.0", base + ".blocks.1.block.1", CONV_K5, a0, -1, cout, 0,
-             cout, L, out, res >= 0 ? res : in0, -1);
-        if (cat_identity) {
-            ConvOp& last = P.convs.back();
-            last.cat0 = in0; last.cat1 = in1; last.cat_c0 = cin0; last.cat_c1 = cin1;
-        }
-        A.put(a0);
-        A.put(res);
-        return out;
-    };
-
-    expect(m, "time_mlp.1.weight", {4 * tdm, c.dim});
-    expect(m, "time_mlp.1.bias", {4 * tdm});
-    expect(m, "time_mlp.3.weight", {tdm, 4 * tdm});
-    expect(m, "time_mlp.3.bias", {tdm});
-
-    const int nl = c.n_levels;
-    int L = c.horizon;
-    int x = -2, cx = c.transition_dim;
-    std::vector<int> skips, skip_ch;
-    for (int i = 0; i < nl; ++i) {
-        const int co = c.channels[i];
-        const std::string b = "downs." + std::to_string(i);
-        const int h1 = res_block(b + ".0", x, -1, cx, 0, co, L);
-        if (x >= 0) A.put(x);
-        const int h2 = res_block(b + ".1", h1, -1, co, 0, co, L);
-        A.put(h1);
-        skips.push_back(h2);
-        skip_ch.push_back(co);
-        if (i < nl - 1) {
-            const int d = A.get((long)co * (L / 2));
-            conv(b + ".2.conv", "", CONV_DOWN, h2, -1, co, 0, co, L, d, -1, -1);
-            L /= 2;
-            x = d;
-            if (i == 0) A.put(h2);   // level-0 skip is pushed but never popped (F8)
-        } else {
-            x = h2;
-        }
-        cx = co;
-    }
-    const int cm = c.channels[nl - 1];
-    const bool x_is_skip = true;   // x aliases skips.back() (last level has no downsample)
-    const int m1 = res_block("mid_block1", x, -1, cm, 0, cm, L);
-    (void)x_is_skip;
-    const int m2 = res_block("mid_block2", m1, -1, cm, 0, cm, L);
-    A.put(m1);
-    x = m2;
-    cx = cm;
-    for (int j = 0; j < nl - 1; ++j) {
-        const int lvl = nl - 1 - j;                 // level whose skip is popped
-        const int skip = skips[lvl];
-        const int cs = skip_ch[lvl];
-        const int co = c.channels[lvl - 1];
-        const std::string b = "ups." + std::to_string(j);
-        const int u1 = res_block(b + ".0", x, skip, cx, cs, co, L);
-        A.put(x);
-        A.put(skip);
-        const int u2 = res_block(b + ".1", u1, -1, co, 0, co, L);
-        A.put(u1);
-        const int up = A.get((long)co * (2 * L));
-        conv(b + ".2.conv", "", CONV_UP, u2, -1, co, 0, co, L, up, -1, -1);
-        A.put(u2);
-        L *= 2;
-        x = up;
-        cx = co;
-    }
-    if (nl == 1) { /* x == skips[0]; nothing popped */ }
-    if (cx != c.dim)
-        return fail(DAD_E_INVALID, "final_conv expects %d channels but the decoder ends with %d "
-                    "(reference requires dim_mults[0] == 1)", c.dim, cx);
-    const int f = A.get((long)c.dim * L);
-    conv("final_conv.0.block.0", "final_conv.0.block.1", CONV_K5, x, -1, cx, 0, c.dim, L, f, -1, -1);
-    P.final_act = f;
-    expect(m, "final_conv.1.weight", {c.transition_dim, c.dim, 1});
-    expect(m, "final_conv.1.bias", {c.transition_dim});
-    P.temb_width = temb_off;
-
-    long off = 0;
-    for (auto& b : P.bufs) {
-        b.offset = off;
-        off += (b.per_sample + 3) / 4 * 4;
-    }
-    P.floats_per_sample = off;
-    return DAD_OK;
-}
-
-// ------------------------------------------------------------------------------ packing
-// Conv1d weight (co, ci, k)  ->  [ci_pad/KC][k][M = co][KC]
-std::vector<float> pack_conv(const HostTensor& w, int cin_pad, int taps, int kc) {
-    const int co = (int)w.shape[0], ci = (int)w.shape[1], k = (int)w.shape[2];
-    std::vector<float> out((size_t)cin_pad * taps * co, 0.0f);
-    for (int o = 0; o < co; ++o)
-        for (int i = 0; i < ci; ++i)
-            for (int t = 0; t < k; ++t) {
-                const size_t row = ((size_t)(i / kc) * taps + t) * co + o;
-                out[row * kc + (i % kc)] = w.data[((size_t)o * ci + i) * k + t];
-            }
-    return out;
-}
-
-// ConvTranspose1d weight (ci, co, 4), stride 2, pad 1:
-//   y[co, 2j]   = sum_ci W[ci,co,3] x[ci,j-1] + W[ci,co,1] x[ci,j]
-//   y[co, 2j+1] = sum_ci W[ci,co,2] x[ci,j]   + W[ci,co,0] x[ci,j+1]
-// packed as a 2-tap conv with M = 2*co columns: columns [0,co) are the even phase (taps at
-// positions j-1, j), columns [co,2co) the odd phase (taps at j, j+1 — the kernel shifts the row
-// base by one for tiles of that half).
-std::vector<float> pack_convT(const HostTensor& w, int cin_pad, int kc) {
-    const int ci = (int)w.shape[0], co = (int)w.shape[1];
-    const int M = 2 * co;
-    std::vector<float> out((size_t)cin_pad * 2 * M, 0.0f);
-    auto at = [&](int i, int o, int kk) { return w.data[((size_t)i * co + o) * 4 + kk]; };
-    for (int i = 0; i < ci; ++i)
-        for (int o = 0; o < co; ++o) {
-            auto slot = [&](int tap, int m) -> float& {
-                return out[(((size_t)(i / kc) * 2 + tap) * M + m) * kc + (i % kc)];
-            };
-            slot(0, o) = at(i, o, 3);
-            slot(1, o) = at(i, o, 1);
-            slot(0, co + o) = at(i, o, 2);
-            slot(1, co + o) = at(i, o, 0);
-        }
-    return out;
-}
-
-// Split-f16 image of a packed weight tensor (granules of 16 input channels):
-//   [8 words: 16 hi halves | 8 words: 16 lo halves],  w * 2^s ~= hi + lo * 2^-11,
-// s chosen per layer so the largest weight lands in [2^9, 2^10) and small ones stay normal halves.
-// The kernel reads the words as the 32x32x16 f16 MFMA operand (conv_gemm.hpp, X3).
-uint16_t f16_bits(float v) {
-    const _Float16 h = (_Float16)v;       // round to nearest even
-    uint16_t b;
-    std::memcpy(&b, &h, 2);
-    return b;
-}
-int split_f16_image(std::vector<float>& packed) {
-    float amax = 0.0f;
-    for (float v : packed) amax = std::max(amax, std::fabs(v));
-    int s = 0;
-    if (amax > 0.0f && std::isfinite(amax)) {
-        int e;
-        std::frexp(amax, &e);             // amax = f * 2^e, f in [0.5, 1)
-        s = 10 - e;                       // amax * 2^s in [2^9, 2^10)
-    }
-    s = std::max(-100, std::min(100, s));
-    const float up = std::ldexp(1.0f, s);
-    for (size_t g = 0; g + 16 <= packed.size(); g += 16) {
-        uint16_t hi[16], lo[16];
-        for (int j = 0; j < 16; ++j) {
-            const float v = packed[g + j] * up;
-            const _Float16 h = (_Float16)v;
-            hi[j] = f16_bits(v);
-            lo[j] = f16_bits((v - (float)h) * 2048.0f);
-        }
-        std::memcpy(&packed[g], hi, 32);
-        std::memcpy(&packed[g + 8], lo, 32);
-    }
-    return s;
-}
-
 int arena_alloc(dad_model* m, size_t bytes, void** out) {
     const size_t aligned = (bytes + 255) / 256 * 256;
     if (m->arena_used + aligned > m->arena_cap)
@@ -428,26 +108,6 @@ int upload(dad_model* m, const std::vector<float>& host, float** dev) {
     return DAD_OK;
 }
 
-// Bytes the arena must hold: packed weights, norms, tables, time-MLP weights, flags.
-size_t arena_bytes_needed(const dad_model* m) {
-    const dad_cfg& c = m->cfg;
-    size_t floats = 0, allocs = 0;
-    auto add = [&](size_t n) { floats += n + 64; ++allocs; };
-    for (const ConvOp& op : m->plan.convs) {
-        add((size_t)op.cin_pad * op.taps * op.M);
-        add(op.M);
-        if (!op.norm.empty()) { add(op.cout); add(op.cout); }
-        if (op.temb_off >= 0) { add((size_t)op.cout * c.time_dim); add(op.cout); }
-    }
-    add((size_t)c.transition_dim * c.dim); add(c.transition_dim);
-    const size_t T = c.n_timesteps;
-    add(T * c.dim); add(T * 4 * c.time_dim); add(T * c.time_dim);
-    add(T * std::max(1, m->plan.temb_width));
-    add((size_t)4 * c.time_dim * c.dim); add(4 * c.time_dim);
-    add((size_t)c.time_dim * 4 * c.time_dim); add(c.time_dim);
-    return floats * sizeof(float) + allocs * 256 + kMaxSplitTiles * sizeof(unsigned) + (1 << 16);
-}
-
 void free_device(dad_model* m) {
     for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     m->graphs.clear();
@@ -455,274 +115,81 @@ void free_device(dad_model* m) {
     m->owned.clear();
     m->arena = nullptr;
     m->arena_cap = m->arena_used = 0;
-    m->d_temb_table = nullptr;
+    m->d_emb = m->d_temb = m->d_temb_table = nullptr;
     m->d_final_w = m->d_final_b = nullptr;
     m->d_rng = nullptr;
     m->d_counters = nullptr;
-    for (auto& op : m->plan.convs) op.d_w = op.d_bias = op.d_gamma = op.d_beta = nullptr;
+    for (auto& op : m->plan.convs) op.d_w = op.d_bias = op.d_gamma = op.d_beta = op.d_rbias = nullptr;
 }
 
-// ------------------------------------------------------------------------- conv launch
-template <int CFG> struct Tile;
-template <> struct Tile<0> { static constexpr int BM = 32, BN = 64, SK = 4, KC = 32; };
-template <> struct Tile<1> { static constexpr int BM = 64, BN = 64, SK = 2, KC = 32; };
-template <> struct Tile<2> { static constexpr int BM = 128, BN = 64, SK = 1, KC = 16; };
-template <> struct Tile<3> { static constexpr int BM = 256, BN = 32, SK = 1, KC = 8; };
-template <> struct Tile<4> { static constexpr int BM = 64, BN = 64, SK = 1, KC = 16; };
-template <> struct Tile<5> { static constexpr int BM = 32, BN = 64, SK = 2, KC = 16; };
-template <> struct Tile<6> { static constexpr int BM = 32, BN = 64, SK = 1, KC = 16; };
-template <> struct Tile<7> { static constexpr int BM = 64, BN = 64, SK = 2, KC = 16; };
+// ---------------------------------------------------------------------- kernel registry
+// Every conv-GEMM instantiation the planner can ask for, keyed by what plan_launch decides.
+using KernFn = void (*)(const ConvParams);
+using KernKey = std::tuple<int, int, int, bool, bool, bool, bool>;   // cfg, taps, stride, x3, bdir, ragged, res
+using KernTable = std::map<KernKey, KernFn>;
 
-// 1x1 convs have one (tap, group) unit per 8 channels: a deep K chunk keeps enough MFMAs between
-// barriers (128 channels; 64 for the 128-row tile, whose stage would not fit LDS twice).
-// Split-f16 kernels consume 16 channels per unit: the chunk must give every split-K wave a unit.
-constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false, bool bd = false) {
-    return bd                          ? 32          // wide tile, direct-B kernel (either arithmetic)
-           : (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128)
-           : (x3 && cfg_kc < 16 * sk)  ? 16 * sk
-                                       : cfg_kc;
-}
+template <int CFG> struct Tile {
+    static constexpr int BM = kTiles[CFG].BM, BN = kTiles[CFG].BN, SK = kTiles[CFG].SK, KC = kTiles[CFG].KC;
+};
 
-template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR = false>
-int launch_conv_t(ConvParams& p, hipStream_t st) {
-    using T = Tile<CFG>;
-    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR);   // BDIR: weight fragments straight from global
-    const int cin = p.cin0 + p.cin1;
-    const bool ragged = (p.cin0 & 3) != 0 || (p.cin1 & 3) != 0 || p.cin0 % KC != 0 || cin % KC != 0;
-    if (ragged && !(STRIDE == 1 && (TAPS == 5 || TAPS == 1)))
-        return fail(DAD_E_INVALID, "channel count %d+%d needs the general staging path, which exists "
-                    "for stride-1 5-tap and 1x1 convs only", p.cin0, p.cin1);
-    if (BDIR && ragged)
-        return fail(DAD_E_INVALID, "the direct-B split-f16 kernel needs whole 32-channel chunks (%d+%d)", p.cin0, p.cin1);
-    auto kern = BDIR ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR>
-                : (ragged && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
-                    ? dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true && !BDIR, X3, BDIR>
-                    : dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR>;
-    const size_t lds = dad::conv_lds_floats(T::BM, T::BN, KC, TAPS, p.Lin, p.Lout, T::SK, BDIR) * sizeof(float);
-    const int spt = T::BN / p.Lout;
-    p.ntiles_n = (p.B + spt - 1) / spt;
-    if (p.ntiles_n > 65535) return fail(DAD_E_INVALID, "batch too large for one launch (%d N tiles)", p.ntiles_n);
-    // XCD-aware tile order when every XCD gets the same whole rectangle of tiles: choose the
-    // gm x gn arrangement of the 8 XCDs that minimises  gn * (weight bytes) + gm * (activation bytes)
-    const int MT = p.M / T::BM, NTn = p.ntiles_n;
-    dim3 grid(p.kslices, MT, NTn);
-    p.xcd_gn = 0;
-    if (g_xcd_order && p.kslices == 1 && (MT & (MT - 1)) == 0 && (long)MT * NTn <= 65535 && ((long)MT * NTn) % 8 == 0) {
-        const double wbytes = (double)p.M * TAPS * (p.cin0 + p.cin1);
-        const double xbytes = (double)p.B * p.Lin * (p.cin0 + p.cin1);
-        double best = -1;
-        for (int gm = 1; gm <= 8; gm *= 2) {
-            const int gn = 8 / gm;
-            if (MT % gm != 0 || NTn % gn != 0) continue;
-            const double cost = gn * wbytes + gm * xbytes;
-            if (best < 0 || cost < best) {
-                best = cost;
-                p.xcd_gn = gn; p.xcd_mts = ilog2(MT / gm); p.xcd_ntn = NTn / gn;
-            }
-        }
-        if (p.xcd_gn > 0) grid = dim3(p.kslices, MT * NTn, 1);
-    }
-    hipLaunchKernelGGL(kern, grid,
-                       dim3(64 * (T::BM / 32) * (T::BN / 32) * T::SK), lds, st, p);
-    HIP_TRY(hipGetLastError());
-    return DAD_OK;
-}
-
-// Every kernel may use up to the full 160 KiB of LDS; raise the dynamic-LDS limit once
-// (not lazily, so that nothing but launches happens under hipGraph capture).
-template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR = false>
-hipError_t raise_lds_limit() {
+template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR, bool RES>
+void reg_kernel(KernTable& t) {
     using T = Tile<CFG>;
     constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR);
-    hipError_t e = hipFuncSetAttribute(
-        (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    if (!BDIR && STRIDE == 1 && (TAPS == 5 || TAPS == 1))
-        e = hipFuncSetAttribute(
-            (const void*)dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, 1, true && !BDIR, X3, BDIR>,
-            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e;
+    t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, false, RES)] =
+        dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR, RES>;
+    if constexpr (!BDIR && STRIDE == 1 && (TAPS == 5 || TAPS == 1))    // general staging path
+        t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, true, RES)] =
+            dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, true, X3, BDIR, RES>;
 }
 template <int CFG>
-hipError_t raise_lds_limit_cfg() {
-    hipError_t e;
-    if ((e = raise_lds_limit<CFG, 5, 1, false>()) != hipSuccess) return e;
-    if ((e = raise_lds_limit<CFG, 3, 2, false>()) != hipSuccess) return e;
-    if ((e = raise_lds_limit<CFG, 2, 1, false>()) != hipSuccess) return e;
-    if ((e = raise_lds_limit<CFG, 1, 1, false>()) != hipSuccess) return e;
-    if constexpr (Tile<CFG>::KC >= 16) {      // split-f16 variants (16-channel granules)
-        if ((e = raise_lds_limit<CFG, 5, 1, true>()) != hipSuccess) return e;
-        if ((e = raise_lds_limit<CFG, 3, 2, true>()) != hipSuccess) return e;
-        if ((e = raise_lds_limit<CFG, 2, 1, true>()) != hipSuccess) return e;
-        if ((e = raise_lds_limit<CFG, 1, 1, true>()) != hipSuccess) return e;
-    } else {                                   // wide tile: the direct-B kernels of the GroupNorm'd 5-tap convs
-        if ((e = raise_lds_limit<CFG, 5, 1, true, true>()) != hipSuccess) return e;
-        if ((e = raise_lds_limit<CFG, 5, 1, false, true>()) != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-int configure_kernels() {
-    static bool done = false;
-    if (done) return DAD_OK;
-    HIP_TRY(raise_lds_limit_cfg<0>());
-    HIP_TRY(raise_lds_limit_cfg<1>());
-    HIP_TRY(raise_lds_limit_cfg<2>());
-    HIP_TRY(raise_lds_limit_cfg<3>());
-    HIP_TRY(raise_lds_limit_cfg<4>());
-    HIP_TRY(raise_lds_limit_cfg<5>());
-    HIP_TRY(raise_lds_limit_cfg<6>());
-    HIP_TRY(raise_lds_limit_cfg<7>());
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-    return DAD_OK;
-}
-
-template <int CFG>
-int launch_conv_cfg(ConvParams& p, int taps, int stride, bool x3, bool bdir, hipStream_t st) {
-    if constexpr (Tile<CFG>::KC == 8) {
-        if (bdir && taps == 5 && stride == 1)
-            return x3 ? launch_conv_t<CFG, 5, 1, true, true>(p, st) : launch_conv_t<CFG, 5, 1, false, true>(p, st);
-    }
-    if (bdir) return fail(DAD_E_INVALID, "no direct-B kernel for tile %d taps=%d stride=%d", CFG, taps, stride);
+void reg_tile(KernTable& t) {
+    reg_kernel<CFG, 5, 1, false, false, false>(t);
+    reg_kernel<CFG, 3, 2, false, false, false>(t);
+    reg_kernel<CFG, 2, 1, false, false, false>(t);
+    reg_kernel<CFG, 1, 1, false, false, false>(t);
     if constexpr (Tile<CFG>::KC >= 16) {
-        if (x3) {
-            if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, true>(p, st);
-            if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2, true>(p, st);
-            if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1, true>(p, st);
-            if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1, true>(p, st);
-        }
+        reg_kernel<CFG, 5, 1, false, false, true>(t);      // + the riding 1x1 residual conv
+        reg_kernel<CFG, 5, 1, true, false, false>(t);      // split-f16 variants (16-channel granules)
+        reg_kernel<CFG, 3, 2, true, false, false>(t);
+        reg_kernel<CFG, 2, 1, true, false, false>(t);
+        reg_kernel<CFG, 1, 1, true, false, false>(t);
+    } else {                                               // wide tile: direct-B kernels of the GroupNorm'd 5-tap convs
+        reg_kernel<CFG, 5, 1, true, true, false>(t);
+        reg_kernel<CFG, 5, 1, false, true, false>(t);
     }
-    if (x3) return fail(DAD_E_INVALID, "no split-f16 kernel for tile %d taps=%d stride=%d", CFG, taps, stride);
-    if (taps == 5 && stride == 1) return launch_conv_t<CFG, 5, 1, false>(p, st);
-    if (taps == 3 && stride == 2) return launch_conv_t<CFG, 3, 2, false>(p, st);
-    if (taps == 2 && stride == 1) return launch_conv_t<CFG, 2, 1, false>(p, st);
-    if (taps == 1 && stride == 1) return launch_conv_t<CFG, 1, 1, false>(p, st);
-    return fail(DAD_E_INVALID, "unsupported conv taps=%d stride=%d", taps, stride);
+}
+const KernTable& kernel_table() {
+    static const KernTable table = [] {
+        KernTable t;
+        reg_tile<0>(t); reg_tile<1>(t); reg_tile<2>(t); reg_tile<3>(t);
+        reg_tile<4>(t); reg_tile<5>(t); reg_tile<6>(t); reg_tile<7>(t);
+        return t;
+    }();
+    return table;
 }
 
-// Tile choice.  Hard constraints: the tile holds whole GroupNorm groups (BM % (C/8) == 0) and
-// whole samples (BN % L == 0), BM divides the columns (each phase half for the transposed
-// conv), the K chunk matches the packed weights.  Preference: enough blocks to cover the 256
-// CUs; when tiles are scarce, trade tile size for split-K depth.
-int choose_tile(const ConvOp& op, int batch) {
-    const int Mrows = op.kind == CONV_UP ? op.M / 2 : op.M;
-    const int cpg = op.norm.empty() ? 1 : op.cout / 8;
-    auto valid = [&](int cfg) {
-        const TileCfg& t = kTiles[cfg];
-        if ((t.KC == 8) != (op.kc == 8)) return false;
-        if (Mrows % t.BM != 0) return false;
-        if (!op.norm.empty() && (t.BM % cpg != 0)) return false;
-        if (t.BN % op.Lout != 0) return false;
-        const int nthreads = 64 * (t.BM / 32) * (t.BN / 32) * t.SK;
-        const int f4pl = t.BM * t.BN / 4 / nthreads;
-        if (!op.norm.empty() && op.Lout * cpg / 4 < f4pl) return false;   // >= 1 lane per (group, sample)
-        return true;
-    };
-    auto blocks = [&](int cfg) {
-        const TileCfg& t = kTiles[cfg];
-        const int spt = t.BN / op.Lout;
-        return (long)((batch + spt - 1) / spt) * (op.M / t.BM);
-    };
-    if (op.kc == 8) return valid(3) ? 3 : -1;
-    if (g_force_tile >= 0 && g_force_tile < 8 && valid(g_force_tile)) return g_force_tile;
-    if (valid(2) && blocks(2) >= 512) return 2;          // plentiful work: big tile
-    if (valid(1) && blocks(1) >= 224) return 1;
-    if (valid(0)) return 0;
-    if (valid(1)) return 1;
-    if (valid(2)) return 2;
-    if (valid(4)) return 4;
-    return -1;
-}
-
-// Per-sample slot shifts of the X stage (conv_gemm.hpp, "Activation rows in LDS and bank
-// conflicts").  Depth-first over the samples of a block tile: d(s) in [0, 16) such that in every
-// 32-row wave tile both 16-lane groups of ds_read_b128 see 16 distinct slots, and no sample is
-// pushed onto its neighbour's real rows (d(s) - d(s+1) <= pad * slots-per-row).  Returns 0 (plain
-// layout — correct, just slower) when L >= 32, when there is no halo, or when nothing is found.
-uint64_t find_xswz(int L, int stride, int pad, int kp4, int BN) {
-    if (L >= 32 || pad == 0 || BN / L > 16) return 0;
-    static std::map<std::vector<int>, uint64_t> cache;
-    static std::mutex cache_lock;
-    std::lock_guard<std::mutex> hold(cache_lock);
-    const std::vector<int> key{L, stride, pad, kp4, BN};
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
-                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
-    const int S = BN / L, seg = L * stride + 2 * pad, per = 32 / L;
-    std::vector<int> d(S, 0);
-    // conflicts among the lanes whose samples are already placed (samples < upto)
-    auto ok_prefix = [&](int upto) {
-        for (int tn = 0; tn * per < upto; ++tn)
-            for (const auto& g : groups) {
-                unsigned seen = 0;
-                for (int lane : g) {
-                    const int n = tn * 32 + lane, sm = n / L, l = n % L;
-                    if (sm >= upto) continue;
-                    const unsigned bit = 1u << (((sm * seg + l * stride) * kp4 + d[sm]) & 15);
-                    if (seen & bit) return false;
-                    seen |= bit;
-                }
-            }
-        return true;
-    };
-    long budget = 300000;                           // node budget: the search is a one-off per shape
-    std::function<bool(int)> place = [&](int sm) -> bool {
-        if (sm == S) return true;
-        for (int v = 0; v < 16; ++v) {
-            if (--budget < 0) return false;
-            if (sm > 0 && d[sm - 1] - v > pad * kp4) continue;
-            d[sm] = v;
-            if (ok_prefix(sm + 1) && place(sm + 1)) return true;
-        }
-        d[sm] = 0;
-        return false;
-    };
-    uint64_t packed = 0;
-    if (place(0))
-        for (int sm = 0; sm < S; ++sm) packed |= (uint64_t)d[sm] << (4 * sm);
-    cache[key] = packed;
-    return packed;
-}
-
-// Grid-level split-K: when a layer has too few output tiles to cover the chip (small batches;
-// the deepest levels of the wide nets), several blocks share a tile and split its K chunks.
-struct SplitPlan { int kslices, chunks_per_slice; long slab_floats; };
-SplitPlan plan_split(const ConvOp& op, int cfg, int batch) {
-    const TileCfg& t = kTiles[cfg];
-    const int spt = t.BN / op.Lout;
-    const long tiles = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
-    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
-    const int nchunks = (op.cin0 + op.cin1 + kc - 1) / kc;      // chunks holding real channels
-    SplitPlan sp{1, nchunks, 0};
-    if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
-    static const int target = getenv("DAD_SPLIT_TARGET") ? atoi(getenv("DAD_SPLIT_TARGET")) : 256;   // tuning aid
-    int want = (int)((target + tiles - 1) / tiles);
-    if (want > nchunks) want = nchunks;
-    if (want < 2) return sp;
-    sp.chunks_per_slice = (nchunks + want - 1) / want;
-    sp.kslices = (nchunks + sp.chunks_per_slice - 1) / sp.chunks_per_slice;
-    sp.slab_floats = tiles * sp.kslices * (long)t.BN * t.BM;
-    return sp;
-}
-
-int choose_tile(const ConvOp& op, int batch);
-
-// floats of split-K scratch a batch needs (max over layers)
-long slab_floats_for(const dad_model* m, int batch) {
-    long best = 0;
-    for (const ConvOp& op : m->plan.convs) {
-        const int cfg = choose_tile(op, batch);
-        if (cfg < 0) continue;
-        best = std::max(best, plan_split(op, cfg, batch).slab_floats);
-    }
-    return best;
+// Every kernel may use up to the full 160 KiB of LDS; the dynamic-LDS limit is a per-device
+// function attribute, raised once per device (not lazily per launch, so that nothing but launches
+// happens under hipGraph capture).
+int configure_kernels() {
+    static std::mutex lock;
+    static std::set<int> done;
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> hold(lock);
+    if (done.count(dev)) return DAD_OK;
+    for (const auto& kv : kernel_table())
+        HIP_TRY(hipFuncSetAttribute((const void*)kv.second, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    done.insert(dev);
+    return DAD_OK;
 }
 
 int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int batch, int t,
@@ -737,6 +204,9 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
                            buf(op.res), buf(op.cat0), buf(op.cat1), rows, op.cat_c0, op.cat_c1);
         HIP_TRY(hipGetLastError());
     }
+    LaunchGeom g;
+    int rc = plan_launch(*m, op, batch, g);
+    if (rc != DAD_OK) return rc;
     ConvParams p{};
     p.src0 = op.src0 == -2 ? xext : buf(op.src0);
     p.src1 = buf(op.src1);
@@ -749,45 +219,34 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout; p.lshift = ilog2(op.Lout);
     p.lshift_in = ilog2(op.Lin);
     p.interleave = op.kind == CONV_UP;
-    if ((long)batch * op.Lout * op.M * (op.kind == CONV_UP ? 1 : 1) >= (1L << 31) ||
-        (long)batch * op.Lin * (op.cin0 + op.cin1) >= (1L << 31))
-        return fail(DAD_E_INVALID, "batch %d too large: a layer's activation tensor exceeds 2^31 elements", batch);
-    const int cfg = choose_tile(op, batch);
-    if (cfg < 0)
-        return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
-                    op.name.c_str(), op.M, op.cout / 8, op.Lout);
-    const SplitPlan sp = g_split_enabled ? plan_split(op, cfg, batch)
-                                         : SplitPlan{1, op.cin_pad, 0};   // one slice: every chunk
-    p.kslices = sp.kslices;
-    p.chunks_per_slice = sp.chunks_per_slice;
+    p.ntiles_n = g.ntiles_n;
+    p.xcd_gn = g.xcd_gn; p.xcd_mts = g.xcd_mts; p.xcd_ntn = g.xcd_ntn;
+    p.kslices = g.split.kslices;
+    p.chunks_per_slice = g.split.chunks_per_slice;
     p.slab = ws + m->plan.floats_per_sample * (long)batch;     // scratch behind the activations
     p.counters = m->d_counters;
     p.c1 = op.c1; p.c2 = op.c2;
-    {
-        const TileCfg& tc = kTiles[cfg];
-        const int kc = eff_kc(tc.KC, tc.BM, op.taps, tc.SK, op.x3, op.bdir);
-        p.xswz = g_xswz_enabled ? find_xswz(op.Lout, op.stride, op.taps / 2, (kc + 4) / 4, tc.BN) : 0;
-    }
+    p.xswz = g.xswz;
+    p.wtaps = op.wtaps();
+    p.rbias = g.fused ? op.d_rbias : nullptr;
+    p.rdst = g.fused ? buf(op.rdst) : nullptr;
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;     // tuning aid
     if (trace)
-        fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d tile=%d (%dx%d SK%d) kslices=%d\n", op.name.c_str(),
-                batch, op.M, op.taps, op.cin0 + op.cin1, op.Lout, cfg, kTiles[cfg].BM, kTiles[cfg].BN,
-                kTiles[cfg].SK, sp.kslices);
+        fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d tile=%d (%dx%d SK%d) kslices=%d%s\n", op.name.c_str(),
+                batch, op.M, op.taps, op.cin0 + op.cin1, op.Lout, g.cfg, kTiles[g.cfg].BM, kTiles[g.cfg].BN,
+                kTiles[g.cfg].SK, g.split.kslices, g.fused ? " +res1x1" : "");
 #ifdef DAD_STAMPS
     p.stamps = g_stamps ? g_stamps + (size_t)(&op - &m->plan.convs[0]) * 4096 * 8 : nullptr;
 #endif
-    int rc;
-    switch (cfg) {
-        case 0: rc = launch_conv_cfg<0>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-        case 1: rc = launch_conv_cfg<1>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-        case 2: rc = launch_conv_cfg<2>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-        case 3: rc = launch_conv_cfg<3>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-        case 4: rc = launch_conv_cfg<4>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-        case 5: rc = launch_conv_cfg<5>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-        case 6: rc = launch_conv_cfg<6>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-        default: rc = launch_conv_cfg<7>(p, op.taps, op.stride, op.x3, op.bdir, st); break;
-    }
-    return rc;
+    const auto& table = kernel_table();
+    const auto it = table.find(KernKey(g.cfg, op.taps, op.stride, op.x3, op.bdir, g.ragged, g.fused));
+    if (it == table.end())
+        return fail(DAD_E_INVALID, "no kernel for %s (tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d)",
+                    op.name.c_str(), g.cfg, op.taps, op.stride, (int)op.x3, (int)op.bdir, (int)g.ragged, (int)g.fused);
+    void* args[] = {&p};
+    HIP_TRY(hipLaunchKernel((const void*)it->second, dim3(g.gx, g.gy, g.gz), dim3(g.threads), args,
+                            g.lds_bytes, st));
+    return DAD_OK;
 }
 
 int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
@@ -797,7 +256,7 @@ int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
     if (t < 0 || t >= m->cfg.n_timesteps)
         return fail(DAD_E_RANGE, "index %d is out of bounds for the schedule of size %d", t,
                     m->cfg.n_timesteps);
-    const size_t need = ((size_t)m->plan.floats_per_sample * batch + (size_t)slab_floats_for(m, batch)) * sizeof(float);
+    const size_t need = workspace_bytes(*m, batch);
     if (ws_bytes < need)
         return fail(DAD_E_WORKSPACE, "workspace has %zu bytes, batch %d needs %zu", ws_bytes, batch,
                     need);
@@ -821,10 +280,15 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
         ++m->ev_used;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    for (const ConvOp& op : m->plan.convs) {
+    const std::vector<ConvOp>& convs = m->plan.convs;
+    for (const ConvOp& op : convs) {
+        // a residual 1x1 conv whose block's first conv carries it at this batch is not launched
+        const bool rides = op.rider_of >= 0 && fused_at(*m, convs[op.rider_of], batch);
+        if (m->profile) m->prof_flops += op.flops_per_sample * batch;
+        if (rides) continue;
         const int rc = run_conv(m, op, x, ws, batch, t, st);
         if (rc != DAD_OK) return rc;
-        if (m->profile) { m->prof_flops += op.flops_per_sample * batch; ++m->prof_launches; }
+        if (m->profile) ++m->prof_launches;
     }
     if (m->profile) HIP_TRY(hipEventRecord(e1, st));
     return DAD_OK;
@@ -860,7 +324,7 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         p.seed_dev = seed_from_device ? (const unsigned long long*)m->d_rng : nullptr;
     }
     const size_t lds = dad::final_lds_floats(c.transition_dim, c.dim) * sizeof(float);
-    if (lds > 160 * 1024)
+    if (lds > dad::kLdsBytes)
         return fail(DAD_E_INVALID, "final 1x1 conv does not fit LDS (td=%d, dim=%d)", c.transition_dim, c.dim);
     const long N = (long)batch * c.horizon;
     hipLaunchKernelGGL(dad::final_posterior_kernel,
@@ -886,10 +350,11 @@ int run_project(const dad_project_args* pa, float alpha, float* x, int batch, in
     p.alpha = alpha;
     p.one_minus_alpha = (float)(1.0 - (double)alpha);
     // rows per block: one while the batch fits one wave of blocks (every CU streams P once),
-    // four beyond that (P is then re-used by four rows per pass)
-    const int rb = batch <= 512 ? 1 : 4;
-    const size_t lds = (size_t)(1 + 16) * rb * p.D * sizeof(float);   // rows + 16 partial sets
-    if (lds > 160 * 1024) return fail(DAD_E_INVALID, "projection dimension D=%d too large", p.D);
+    // four beyond that (P is then re-used by four rows per pass) if four rows fit LDS
+    const size_t row_lds = (size_t)(1 + 16) * p.D * sizeof(float);    // a row + its 16 partial sets
+    const int rb = (batch > 512 && 4 * row_lds <= dad::kLdsBytes) ? 4 : 1;
+    const size_t lds = rb * row_lds;
+    if (lds > dad::kLdsBytes) return fail(DAD_E_INVALID, "projection dimension D=%d too large", p.D);
     if (rb == 1)
         hipLaunchKernelGGL((dad::project_kernel<1, 16>), dim3(batch), dim3(1024), lds, st, p);
     else
@@ -908,26 +373,16 @@ const char* dad_version(void) { return "dad-hip 0.1 (gfx950, fp32 MFMA)"; }
 
 int dad_model_create(const dad_cfg* cfg, dad_model** out) {
     if (!cfg || !out) return fail(DAD_E_INVALID, "null argument");
-    if (cfg->kernel_size != 5) return fail(DAD_E_INVALID, "kernel_size %d unsupported (5 only)", cfg->kernel_size);
-    if (cfg->n_levels < 1 || cfg->n_levels > DAD_MAX_LEVELS)
-        return fail(DAD_E_INVALID, "n_levels %d out of range", cfg->n_levels);
-    if (cfg->transition_dim < 1 || cfg->dim < 4 || (cfg->dim & 1) || cfg->time_dim < 1)
-        return fail(DAD_E_INVALID, "bad transition_dim/dim/time_dim");
-    if (!is_pow2(cfg->horizon) || (cfg->horizon >> (cfg->n_levels - 1)) < 4)
-        return fail(DAD_E_INVALID, "horizon %d must be a power of two with horizon / 2^(levels-1) >= 4",
-                    cfg->horizon);
-    if (cfg->n_timesteps < 1) return fail(DAD_E_INVALID, "n_timesteps must be positive");
-    for (int i = 0; i < cfg->n_levels; ++i) {
-        const int ch = cfg->channels[i];
-        if (ch < 32 || ch % 32 != 0 || !is_pow2(ch / 8))
-            return fail(DAD_E_INVALID, "level %d has %d channels: need a multiple of 32 with C/8 a power of two",
-                        i, ch);
-    }
-    if (cfg->dim % 32 != 0) return fail(DAD_E_INVALID, "dim %d must be a multiple of 32", cfg->dim);
+    int rc = check_cfg(cfg);
+    if (rc != DAD_OK) return rc;
     std::unique_ptr<dad_model> m(new dad_model());
     m->cfg = *cfg;
-    const int rc = build_plan(m.get());
-    if (rc != DAD_OK) return rc;
+    // A/B switches for tuning runs (read once, per model)
+    m->xswz_enabled = getenv("DAD_NO_XSWZ") == nullptr;
+    m->xcd_order = getenv("DAD_NO_XCD_ORDER") == nullptr;
+    m->fuse_residual = getenv("DAD_NO_FUSE_RES") == nullptr;
+    if (const char* v = getenv("DAD_SPLIT_TARGET")) m->split_target = std::max(1, atoi(v));
+    if ((rc = build_plan(m.get())) != DAD_OK) return rc;
     *out = m.release();
     return DAD_OK;
 }
@@ -969,6 +424,16 @@ int dad_model_load_schedule(dad_model* m, const float* a, const float* b, const 
     return DAD_OK;
 }
 
+int dad_model_load_time_embedding(dad_model* m, const float* emb, int32_t n_timesteps, int32_t dim) {
+    if (!m || !emb) return fail(DAD_E_INVALID, "null argument");
+    if (n_timesteps != m->cfg.n_timesteps || dim != m->cfg.dim)
+        return fail(DAD_E_INVALID, "time embedding must be (%d, %d), got (%d, %d)", m->cfg.n_timesteps,
+                    m->cfg.dim, n_timesteps, dim);
+    m->emb_override.assign(emb, emb + (size_t)n_timesteps * dim);
+    m->finalized = false;
+    return DAD_OK;
+}
+
 int dad_model_set_precision(dad_model* m, int32_t precision) {
     if (!m) return fail(DAD_E_INVALID, "null model");
     if (precision != DAD_PREC_FP32 && precision != DAD_PREC_F16X3)
@@ -993,43 +458,21 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     const dad_cfg& c = m->cfg;
     {
         void* a = nullptr;
-        m->arena_cap = arena_bytes_needed(m);
+        m->arena_cap = arena_bytes_needed(*m);
         HIP_TRY(hipMalloc(&a, m->arena_cap));
         m->owned.push_back(a);
         m->arena = (char*)a;
         m->arena_used = 0;
     }
 
+    HIP_TRY(hipGetDevice(&m->device));
     for (ConvOp& op : m->plan.convs) {
-        const HostTensor& w = m->raw[op.name + ".weight"];
-        const HostTensor& b = m->raw[op.name + ".bias"];
-        // wide-group layers (op.kc == 8) use the direct-B kernel in either arithmetic: 16-channel
-        // granules, whole 32-channel chunks, 5-tap stride-1 only (else the LDS-staged wide kernel)
-        const int cin_all = op.cin0 + op.cin1;
-        op.bdir = op.kc == 8 && op.kind == CONV_K5 &&
-                  (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
-        const int pack_g = op.bdir ? 16 : op.kc;
-        std::vector<float> packed = op.kind == CONV_UP ? pack_convT(w, op.cin_pad, pack_g)
-                                                       : pack_conv(w, op.cin_pad, op.taps, pack_g);
-        // split-f16 operands where the kernels exist for every tile this layer may get: 16-channel
-        // granules, and for the strided / transposed convs (no general staging path) whole
-        // 64-channel chunks
-        const int cin = op.cin0 + op.cin1;
-        op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
-                (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
-                            (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
-                             ((op.cin0 & 63) == 0 && (cin & 63) == 0)));
-        op.c1 = 1.0f; op.c2 = 0.0f;
-        if (op.x3) {
-            const int sh = split_f16_image(packed);
-            op.c1 = std::ldexp(1.0f, -sh);
-            op.c2 = std::ldexp(1.0f, -sh - 11);
-        }
-        int rc = upload(m, packed, &op.d_w);
+        PackedOp packed;
+        int rc = pack_op(m, op, packed);
         if (rc != DAD_OK) return rc;
-        std::vector<float> bias = b.data;
-        if (op.kind == CONV_UP) bias.insert(bias.end(), b.data.begin(), b.data.end());
-        if ((rc = upload(m, bias, &op.d_bias)) != DAD_OK) return rc;
+        if ((rc = upload(m, packed.w, &op.d_w)) != DAD_OK) return rc;
+        if ((rc = upload(m, packed.bias, &op.d_bias)) != DAD_OK) return rc;
+        if (op.ride && (rc = upload(m, packed.rbias, &op.d_rbias)) != DAD_OK) return rc;
         if (!op.norm.empty()) {
             if ((rc = upload(m, m->raw[op.norm + ".weight"].data, &op.d_gamma)) != DAD_OK) return rc;
             if ((rc = upload(m, m->raw[op.norm + ".bias"].data, &op.d_beta)) != DAD_OK) return rc;
@@ -1041,19 +484,13 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
 
     // ---- time-embedding tables: every t in [0, T) at once --------------------------------
     const int T = c.n_timesteps, dim = c.dim, tdm = c.time_dim;
-    std::vector<float> emb((size_t)T * dim);
-    {   // SinusoidalPosEmb (temporal_unet.py:27-31) in fp32, as torch computes it
-        const int half = dim / 2;
-        const float scale = (float)(-(std::log(10000.0) / (half - 1)));
-        for (int t = 0; t < T; ++t)
-            for (int j = 0; j < half; ++j) {
-                const float f = std::exp((float)j * scale);
-                const float arg = (float)t * f;
-                emb[(size_t)t * dim + j] = std::sin(arg);
-                emb[(size_t)t * dim + half + j] = std::cos(arg);
-            }
-    }
+    // SinusoidalPosEmb (temporal_unet.py:27-31): the caller's table when one was handed over
+    // (dad_model_load_time_embedding: the Python mirror evaluates the reference's own torch
+    // expression), else the same formula with the C library's expf/sinf/cosf
+    const std::vector<float> emb = m->emb_override.size() == (size_t)T * dim ? m->emb_override
+                                                                            : sinusoid_table(T, dim);
     float *d_emb, *d_h1, *d_temb, *d_w, *d_b;
+    (void)c;
     if ((rc = upload(m, emb, &d_emb)) != DAD_OK) return rc;
     std::vector<float> zeros((size_t)T * 4 * tdm, 0.0f);
     if ((rc = upload(m, zeros, &d_h1)) != DAD_OK) return rc;
@@ -1061,6 +498,7 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     if ((rc = upload(m, zeros, &d_temb)) != DAD_OK) return rc;
     zeros.assign((size_t)T * std::max(1, m->plan.temb_width), 0.0f);
     if ((rc = upload(m, zeros, &m->d_temb_table)) != DAD_OK) return rc;
+    m->d_emb = d_emb; m->d_temb = d_temb;
     auto linear = [&](const float* in, const std::string& key, float* out, int K, int M, int stride,
                       int mish_in) -> int {
         int r;
@@ -1095,7 +533,7 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
 
 int dad_workspace_bytes(const dad_model* m, int32_t batch, size_t* bytes) {
     if (!m || !bytes || batch <= 0) return fail(DAD_E_INVALID, "bad argument");
-    *bytes = ((size_t)m->plan.floats_per_sample * (size_t)batch + (size_t)slab_floats_for(m, batch)) * sizeof(float);
+    *bytes = workspace_bytes(*m, batch);
     return DAD_OK;
 }
 
@@ -1170,8 +608,16 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     }
     GraphKey key{};
     key.x = x; key.noise = noise_stack; key.cond = cond0; key.ws = workspace;
-    key.P = proj ? proj->P : nullptr;
+    if (proj) {
+        key.P = proj->P; key.obs_mean = proj->obs_mean; key.obs_std = proj->obs_std;
+        key.act_mean = proj->act_mean; key.act_std = proj->act_std;
+        key.state_dim = proj->state_dim; key.observation_dim = proj->observation_dim;
+        key.action_dim = proj->action_dim;
+    }
     key.n_steps = n_steps; key.batch = batch; key.cond_per_row = cond_per_row;
+    key.force_tile = m->force_tile;
+    key.flags = (m->split_enabled ? 1 : 0) | (m->fuse_residual ? 2 : 0) | (m->xswz_enabled ? 4 : 0) |
+                (m->xcd_order ? 8 : 0) | (m->split_target << 8);
     key.row_offset = row_offset;
     if (proj) {
         uint64_t hsh = 1469598103934665603ull;            // FNV-1a over the per-step alphas
@@ -1185,6 +631,9 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         if (m->graphs.size() >= 16) {                 // bounded cache: drop everything, re-capture
+            // a replay may still be in flight on the caller's stream (or on another one the caller
+            // used earlier): wait for the device before destroying executable graphs
+            HIP_TRY(hipDeviceSynchronize());
             for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
             m->graphs.clear();
         }
@@ -1221,10 +670,52 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, u
 int dad_debug_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return DAD_OK; }
 #endif
 
-int dad_debug_set_tile(int32_t cfg) {
+int dad_debug_set_tile(dad_model* m, int32_t cfg) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
     // cfg >= 100: same, with grid-level split-K disabled (cfg - 100 is the tile, 99 = heuristic)
-    g_split_enabled = cfg < 99;
-    g_force_tile = cfg >= 99 ? cfg - 100 : cfg;
+    m->split_enabled = cfg < 99;
+    m->force_tile = cfg >= 99 ? cfg - 100 : cfg;
+    return DAD_OK;
+}
+
+int dad_debug_set_option(dad_model* m, const char* name, int32_t value) {
+    if (!m || !name) return fail(DAD_E_INVALID, "null argument");
+    const std::string key(name);
+    if (key == "fuse_residual") m->fuse_residual = value != 0;
+    else if (key == "xswz") m->xswz_enabled = value != 0;
+    else if (key == "xcd_order") m->xcd_order = value != 0;
+    else if (key == "split_target") m->split_target = std::max(1, (int)value);
+    else return fail(DAD_E_INVALID, "unknown option '%s'", name);
+    return DAD_OK;
+}
+
+int dad_debug_read_table(dad_model* m, int32_t which, int32_t t, float* host_out, int32_t capacity,
+                         int32_t* width_out) {
+    if (!m || !host_out) return fail(DAD_E_INVALID, "null argument");
+    if (!m->finalized) return fail(DAD_E_STATE, "dad_model_finalize has not been called");
+    if (t < 0 || t >= m->cfg.n_timesteps)
+        return fail(DAD_E_RANGE, "index %d is out of bounds for the schedule of size %d", t, m->cfg.n_timesteps);
+    const float* base = nullptr;
+    int width = 0;
+    switch (which) {
+        case DAD_TABLE_SINUSOID: base = m->d_emb; width = m->cfg.dim; break;
+        case DAD_TABLE_TIME_MLP: base = m->d_temb; width = m->cfg.time_dim; break;
+        case DAD_TABLE_BLOCKS: base = m->d_temb_table; width = m->plan.temb_width; break;
+        default: return fail(DAD_E_INVALID, "unknown table %d", which);
+    }
+    if (width_out) *width_out = width;
+    if (capacity < width)
+        return fail(DAD_E_INVALID, "table %d has rows of %d floats, the buffer holds %d", which, width, capacity);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, base + (size_t)t * width, (size_t)width * sizeof(float), hipMemcpyDeviceToHost));
+    return DAD_OK;
+}
+
+int dad_debug_mish(const float* in, float* out, int64_t n, dad_stream_t stream) {
+    if (!in || !out || n <= 0) return fail(DAD_E_INVALID, "bad argument");
+    hipLaunchKernelGGL(dad::mish_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, (long)n);
+    HIP_TRY(hipGetLastError());
     return DAD_OK;
 }
 

@@ -1,0 +1,723 @@
+// host_plan.hpp — everything libdad_hip.so decides on the HOST before a kernel is launched:
+// validation of the architecture, the launch plan of TemporalUnet.forward, workspace layout,
+// weight packing (fp32 and split-f16 images), tile choice, grid-level split-K, the LDS slot
+// shifts and the launch geometry of every conv-GEMM.  Plain C++17, no HIP: dad_lib.hip includes
+// it for the product, tests/sanitize/host_check.cpp compiles it host-only under
+// -fsanitize=address,undefined.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dad.h"
+#include "conv_shapes.hpp"
+
+namespace dadhost {
+
+inline thread_local char g_err[1024] = "";
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+enum ConvKind { CONV_K5 = 0, CONV_1X1 = 1, CONV_DOWN = 2, CONV_UP = 3 };
+
+// One conv-GEMM launch of the plan.  Buffer ids index Plan::bufs; -1 = none,
+// -2 = the external (B,H,td) trajectory tensor.
+struct ConvOp {
+    std::string name;        // weight key prefix, e.g. "downs.0.0.blocks.0.block.0"
+    std::string norm;        // GroupNorm key prefix or ""
+    ConvKind kind;
+    int taps, stride;
+    int cin0, cin1, cin_pad;
+    int cout;                // real output channels
+    int M;                   // GEMM rows (2*cout for CONV_UP)
+    int Lin, Lout;           // GEMM per-sample lengths (CONV_UP: Lout == Lin, stores 2*Lin)
+    int src0, src1, dst, res;
+    int temb_off;            // offset into the per-t table, or -1
+    int kc = 16;             // K chunk the weights are packed for (8 when C_out/8 == 256)
+    bool x3 = false;         // weights packed as split-f16 images (dad_model_set_precision)
+    bool bdir = false;       // wide tile: weight fragments go global -> registers
+    // identity residual over a channel concat (decoder block whose 2*C_in equals C_out): the two
+    // halves are copied side by side into the `res` buffer before this launch
+    int cat0 = -1, cat1 = -1, cat_c0 = 0, cat_c1 = 0;
+    // The 1x1 residual conv of a ResidualTemporalBlock reads exactly the rows the block's first
+    // 5-tap conv stages (temporal_unet.py:117-121).  It exists in the plan as its own launch
+    // (rider_of = index of that conv) and, where the kernel variant exists, ALSO as a sixth
+    // "tap" inside that conv's weight image (rname/rdst; own accumulator, plain bias epilogue).
+    // Which of the two runs is decided per batch (fused_at): the ride needs the whole K in one
+    // block, so batches small enough for grid-level split-K keep the separate launch.
+    std::string rname;       // weight key prefix of the riding residual conv, or ""
+    int rdst = -1;           // buffer the ride writes
+    bool ride = false;       // weight image holds the sixth tap (decided at pack time)
+    int rider_of = -1;       // this op is the stand-alone form of convs[rider_of]'s ride
+    float c1 = 1.0f, c2 = 0.0f;   // x3: output scales 2^-s and 2^-(s+11)
+    // device tensors (owned by the model)
+    float* d_w = nullptr;
+    float* d_bias = nullptr;
+    float* d_gamma = nullptr;
+    float* d_beta = nullptr;
+    float* d_rbias = nullptr;
+    double flops_per_sample = 0;
+    int wtaps() const { return taps + (ride ? 1 : 0); }      // tap slots of the packed image
+};
+
+struct Buf {
+    long per_sample;   // floats per batch row
+    long offset;       // floats per batch row, from workspace start
+};
+
+struct Plan {
+    std::vector<ConvOp> convs;
+    std::vector<Buf> bufs;
+    long floats_per_sample = 0;
+    int final_act = -1;       // buffer holding final_conv[0] output
+    int temb_width = 0;       // sum of C_out over residual blocks
+};
+
+constexpr int kMaxSplitTiles = 4096;
+struct TileCfg { int BM, BN, SK, KC; };
+// Block tile (BM channels x BN positions), SK-way intra-block split-K, K chunk.  Every
+// configuration runs 8 waves per block except the last three.
+constexpr int kNumTiles = 8;
+constexpr TileCfg kTiles[kNumTiles] = {
+    {32, 64, 4, 32},    // 0: few output tiles -> deepest split-K
+    {64, 64, 2, 32},    // 1: the workhorse at batch 256
+    {128, 64, 1, 16},   // 2: GroupNorm groups of 128 channels / plentiful tiles
+    {256, 32, 1, 8},    // 3: GroupNorm groups of 256 channels (C = 2048)
+    {64, 64, 1, 16},    // 4: plentiful tiles, 4 waves
+    {32, 64, 2, 16},    // 5: 4 waves, small LDS: several independent blocks per CU
+    {32, 64, 1, 16},    // 6: 2 waves
+    {64, 64, 2, 16},    // 7: as 1 with the shallower K chunk (two blocks per CU fit)
+};
+
+// 1x1 convs have one (tap, group) unit per 8 channels: a deep K chunk keeps enough MFMAs between
+// barriers (128 channels; 64 for the 128-row tile, whose stage would not fit LDS twice).
+// Split-f16 kernels consume 16 channels per unit: the chunk must give every split-K wave a unit.
+constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false, bool bd = false) {
+    return bd                          ? 32          // wide tile, direct-B kernel (either arithmetic)
+           : (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128)
+           : (x3 && cfg_kc < 16 * sk)  ? 16 * sk
+                                       : cfg_kc;
+}
+
+// Host half of a model: what exists before any device allocation.
+struct HostModel {
+    dad_cfg cfg{};
+    std::map<std::string, HostTensor> raw;
+    std::map<std::string, std::vector<int64_t>> expected;     // key -> shape
+    Plan plan;
+    int precision = DAD_PREC_FP32;                             // dad_model_set_precision
+    // tuning / test hooks (dad_debug_set_tile) — per model, nothing process-wide
+    int force_tile = -1;
+    bool split_enabled = true;
+    bool fuse_residual = true;                                 // 1x1 residual conv rides in conv0
+    bool xswz_enabled = true;
+    bool xcd_order = true;
+    int split_target = 256;
+    std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo
+};
+
+inline int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ----------------------------------------------------------------------------- validation
+inline int check_cfg(const dad_cfg* cfg) {
+    if (!cfg) return fail(DAD_E_INVALID, "null argument");
+    if (cfg->kernel_size != 5) return fail(DAD_E_INVALID, "kernel_size %d unsupported (5 only)", cfg->kernel_size);
+    if (cfg->n_levels < 1 || cfg->n_levels > DAD_MAX_LEVELS)
+        return fail(DAD_E_INVALID, "n_levels %d out of range", cfg->n_levels);
+    if (cfg->transition_dim < 1 || cfg->dim < 4 || (cfg->dim & 1) || cfg->time_dim < 1)
+        return fail(DAD_E_INVALID, "bad transition_dim/dim/time_dim");
+    if (!is_pow2(cfg->horizon) || (cfg->horizon >> (cfg->n_levels - 1)) < 4)
+        return fail(DAD_E_INVALID, "horizon %d must be a power of two with horizon / 2^(levels-1) >= 4",
+                    cfg->horizon);
+    if (cfg->n_timesteps < 1) return fail(DAD_E_INVALID, "n_timesteps must be positive");
+    for (int i = 0; i < cfg->n_levels; ++i) {
+        const int ch = cfg->channels[i];
+        if (ch < 32 || ch % 32 != 0 || !is_pow2(ch / 8))
+            return fail(DAD_E_INVALID, "level %d has %d channels: need a multiple of 32 with C/8 a power of two",
+                        i, ch);
+    }
+    if (cfg->dim % 32 != 0) return fail(DAD_E_INVALID, "dim %d must be a multiple of 32", cfg->dim);
+    return DAD_OK;
+}
+
+// ----------------------------------------------------------------------------- planning
+struct Allocator {
+    std::vector<Buf>& bufs;
+    std::vector<bool> in_use;
+    explicit Allocator(std::vector<Buf>& b) : bufs(b) {}
+    int get(long per_sample) {
+        int best = -1;
+        for (size_t i = 0; i < bufs.size(); ++i)
+            if (!in_use[i] && bufs[i].per_sample >= per_sample &&
+                (best < 0 || bufs[i].per_sample < bufs[best].per_sample))
+                best = (int)i;
+        if (best < 0) {
+            bufs.push_back({per_sample, 0});
+            in_use.push_back(false);
+            best = (int)bufs.size() - 1;
+        }
+        in_use[best] = true;
+        return best;
+    }
+    void put(int id) { if (id >= 0) in_use[id] = false; }
+};
+
+inline void expect(HostModel* m, const std::string& key, std::vector<int64_t> shape) {
+    m->expected[key] = std::move(shape);
+}
+
+// Emits the launch plan of TemporalUnet.forward (temporal_unet.py:199-241) including the
+// reference's always-upsample decoder and unused level-0 skip.
+inline int build_plan(HostModel* m) {
+    const dad_cfg& c = m->cfg;
+    Plan& P = m->plan;
+    P = Plan();
+    m->expected.clear();
+    Allocator A(P.bufs);
+    const int k = c.kernel_size;
+    const int tdm = c.time_dim;
+    int temb_off = 0;
+
+    auto conv = [&](const std::string& name, const std::string& norm, ConvKind kind, int src0,
+                    int src1, int cin0, int cin1, int cout, int Lin, int dst, int res,
+                    int toff) {
+        ConvOp op;
+        op.name = name; op.norm = norm; op.kind = kind;
+        op.cin0 = cin0; op.cin1 = cin1;
+        op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
+        const int padto = op.kc == 8 ? 8 : (kind == CONV_1X1 ? 128 : 64);   // deepest K chunk of its kernels
+        op.cin_pad = (cin0 + cin1 + padto - 1) / padto * padto;
+        op.cout = cout; op.src0 = src0; op.src1 = src1; op.dst = dst; op.res = res;
+        op.temb_off = toff; op.Lin = Lin;
+        const int cin = cin0 + cin1;
+        switch (kind) {
+            case CONV_K5: op.taps = k; op.stride = 1; op.M = cout; op.Lout = Lin;
+                expect(m, name + ".weight", {cout, cin, k});
+                op.flops_per_sample = 2.0 * cout * cin * k * Lin; break;
+            case CONV_1X1: op.taps = 1; op.stride = 1; op.M = cout; op.Lout = Lin;
+                expect(m, name + ".weight", {cout, cin, 1});
+                op.flops_per_sample = 2.0 * cout * cin * Lin; break;
+            case CONV_DOWN: op.taps = 3; op.stride = 2; op.M = cout; op.Lout = Lin / 2;
+                expect(m, name + ".weight", {cout, cin, 3});
+                op.flops_per_sample = 2.0 * cout * cin * 3 * (Lin / 2); break;
+            case CONV_UP: op.taps = 2; op.stride = 1; op.M = 2 * cout; op.Lout = Lin;
+                expect(m, name + ".weight", {cin, cout, 4});
+                op.flops_per_sample = 2.0 * cout * cin * 4 * Lin; break;   // algorithmic
+        }
+        expect(m, name + ".bias", {cout});
+        if (!norm.empty()) {
+            expect(m, norm + ".weight", {cout});
+            expect(m, norm + ".bias", {cout});
+        }
+        P.convs.push_back(op);
+    };
+
+    auto res_block = [&](const std::string& base, int in0, int in1, int cin0, int cin1, int cout,
+                         int L) -> int {
+        const int cin = cin0 + cin1;
+        const int toff = temb_off;
+        temb_off += cout;
+        expect(m, base + ".time_mlp.1.weight", {cout, tdm});
+        expect(m, base + ".time_mlp.1.bias", {cout});
+        const int a0 = A.get((long)cout * L);
+        conv(base + ".blocks.0.block.0", base + ".blocks.0.block.1", CONV_K5, in0, in1, cin0, cin1,
+             cout, L, a0, -1, toff);
+        int res = -1;
+        const bool cat_identity = cin == cout && in1 >= 0;   // nn.Identity over torch.cat([x, skip])
+        if (cin != cout) {
+            res = A.get((long)cout * L);
+            const int c0 = (int)P.convs.size() - 1;
+            conv(base + ".residual_conv", "", CONV_1X1, in0, in1, cin0, cin1, cout, L, res, -1, -1);
+            if (P.convs[c0].kc == 16) {          // LDS-staged weights: a sixth tap can ride
+                P.convs[c0].rname = base + ".residual_conv";
+                P.convs[c0].rdst = res;
+                P.convs.back().rider_of = c0;
+            }
+        } else if (cat_identity) {
+            res = A.get((long)cout * L);
+        }
+        const int out = A.get((long)cout * L);
+        conv(base + ".blocks.1.block.0", base + ".blocks.1.block.1", CONV_K5, a0, -1, cout, 0,
+             cout, L, out, res >= 0 ? res : in0, -1);
+        if (cat_identity) {
+            ConvOp& last = P.convs.back();
+            last.cat0 = in0; last.cat1 = in1; last.cat_c0 = cin0; last.cat_c1 = cin1;
+        }
+        A.put(a0);
+        A.put(res);
+        return out;
+    };
+
+    expect(m, "time_mlp.1.weight", {4 * tdm, c.dim});
+    expect(m, "time_mlp.1.bias", {4 * tdm});
+    expect(m, "time_mlp.3.weight", {tdm, 4 * tdm});
+    expect(m, "time_mlp.3.bias", {tdm});
+
+    const int nl = c.n_levels;
+    int L = c.horizon;
+    int x = -2, cx = c.transition_dim;
+    std::vector<int> skips, skip_ch;
+    for (int i = 0; i < nl; ++i) {
+        const int co = c.channels[i];
+        const std::string b = "downs." + std::to_string(i);
+        const int h1 = res_block(b + ".0", x, -1, cx, 0, co, L);
+        if (x >= 0) A.put(x);
+        const int h2 = res_block(b + ".1", h1, -1, co, 0, co, L);
+        A.put(h1);
+        skips.push_back(h2);
+        skip_ch.push_back(co);
+        if (i < nl - 1) {
+            const int d = A.get((long)co * (L / 2));
+            conv(b + ".2.conv", "", CONV_DOWN, h2, -1, co, 0, co, L, d, -1, -1);
+            L /= 2;
+            x = d;
+            if (i == 0) A.put(h2);   // level-0 skip is pushed but never popped (F8)
+        } else {
+            x = h2;
+        }
+        cx = co;
+    }
+    const int cm = c.channels[nl - 1];
+    const int m1 = res_block("mid_block1", x, -1, cm, 0, cm, L);
+    const int m2 = res_block("mid_block2", m1, -1, cm, 0, cm, L);
+    A.put(m1);
+    x = m2;
+    cx = cm;
+    for (int j = 0; j < nl - 1; ++j) {
+        const int lvl = nl - 1 - j;                 // level whose skip is popped
+        const int skip = skips[lvl];
+        const int cs = skip_ch[lvl];
+        const int co = c.channels[lvl - 1];
+        const std::string b = "ups." + std::to_string(j);
+        const int u1 = res_block(b + ".0", x, skip, cx, cs, co, L);
+        A.put(x);
+        A.put(skip);
+        const int u2 = res_block(b + ".1", u1, -1, co, 0, co, L);
+        A.put(u1);
+        const int up = A.get((long)co * (2 * L));
+        conv(b + ".2.conv", "", CONV_UP, u2, -1, co, 0, co, L, up, -1, -1);
+        A.put(u2);
+        L *= 2;
+        x = up;
+        cx = co;
+    }
+    if (cx != c.dim)
+        return fail(DAD_E_INVALID, "final_conv expects %d channels but the decoder ends with %d "
+                    "(reference requires dim_mults[0] == 1)", c.dim, cx);
+    const int f = A.get((long)c.dim * L);
+    conv("final_conv.0.block.0", "final_conv.0.block.1", CONV_K5, x, -1, cx, 0, c.dim, L, f, -1, -1);
+    P.final_act = f;
+    expect(m, "final_conv.1.weight", {c.transition_dim, c.dim, 1});
+    expect(m, "final_conv.1.bias", {c.transition_dim});
+    P.temb_width = temb_off;
+
+    long off = 0;
+    for (auto& b : P.bufs) {
+        b.offset = off;
+        off += (b.per_sample + 3) / 4 * 4;
+    }
+    P.floats_per_sample = off;
+    return DAD_OK;
+}
+
+// ------------------------------------------------------------------------------ packing
+// Conv1d weight (co, ci, k)  ->  [ci_pad/KC][wtaps][M = co][KC]; tap index `tap_at + t`.
+inline void pack_conv_into(std::vector<float>& out, const HostTensor& w, int wtaps, int tap_at, int kc) {
+    const int co = (int)w.shape[0], ci = (int)w.shape[1], k = (int)w.shape[2];
+    for (int o = 0; o < co; ++o)
+        for (int i = 0; i < ci; ++i)
+            for (int t = 0; t < k; ++t) {
+                const size_t row = ((size_t)(i / kc) * wtaps + tap_at + t) * co + o;
+                out[row * kc + (i % kc)] = w.data[((size_t)o * ci + i) * k + t];
+            }
+}
+inline std::vector<float> pack_conv(const HostTensor& w, int cin_pad, int taps, int kc) {
+    std::vector<float> out((size_t)cin_pad * taps * (size_t)w.shape[0], 0.0f);
+    pack_conv_into(out, w, taps, 0, kc);
+    return out;
+}
+
+// ConvTranspose1d weight (ci, co, 4), stride 2, pad 1:
+//   y[co, 2j]   = sum_ci W[ci,co,3] x[ci,j-1] + W[ci,co,1] x[ci,j]
+//   y[co, 2j+1] = sum_ci W[ci,co,2] x[ci,j]   + W[ci,co,0] x[ci,j+1]
+// packed as a 2-tap conv with M = 2*co columns: columns [0,co) are the even phase (taps at
+// positions j-1, j), columns [co,2co) the odd phase (taps at j, j+1 — the kernel shifts the row
+// base by one for tiles of that half).
+inline std::vector<float> pack_convT(const HostTensor& w, int cin_pad, int kc) {
+    const int ci = (int)w.shape[0], co = (int)w.shape[1];
+    const int M = 2 * co;
+    std::vector<float> out((size_t)cin_pad * 2 * M, 0.0f);
+    auto at = [&](int i, int o, int kk) { return w.data[((size_t)i * co + o) * 4 + kk]; };
+    for (int i = 0; i < ci; ++i)
+        for (int o = 0; o < co; ++o) {
+            auto slot = [&](int tap, int mm) -> float& {
+                return out[(((size_t)(i / kc) * 2 + tap) * M + mm) * kc + (i % kc)];
+            };
+            slot(0, o) = at(i, o, 3);
+            slot(1, o) = at(i, o, 1);
+            slot(0, co + o) = at(i, o, 2);
+            slot(1, co + o) = at(i, o, 0);
+        }
+    return out;
+}
+
+// Split-f16 image of a packed weight tensor (granules of 16 input channels):
+//   [8 words: 16 hi halves | 8 words: 16 lo halves],  w * 2^s ~= hi + lo * 2^-11,
+// s chosen per layer so the largest weight lands in [2^9, 2^10) and small ones stay normal halves.
+// The kernel reads the words as the 32x32x16 f16 MFMA operand (conv_gemm.hpp, X3).
+inline uint16_t f16_bits(float v) {
+    const _Float16 h = (_Float16)v;       // round to nearest even
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+inline int split_f16_image(std::vector<float>& packed) {
+    float amax = 0.0f;
+    for (float v : packed) amax = std::max(amax, std::fabs(v));
+    int s = 0;
+    if (amax > 0.0f && std::isfinite(amax)) {
+        int e;
+        std::frexp(amax, &e);             // amax = f * 2^e, f in [0.5, 1)
+        s = 10 - e;                       // amax * 2^s in [2^9, 2^10)
+    }
+    s = std::max(-100, std::min(100, s));
+    const float up = std::ldexp(1.0f, s);
+    for (size_t g = 0; g + 16 <= packed.size(); g += 16) {
+        uint16_t hi[16], lo[16];
+        for (int j = 0; j < 16; ++j) {
+            const float v = packed[g + j] * up;
+            const _Float16 h = (_Float16)v;
+            hi[j] = f16_bits(v);
+            lo[j] = f16_bits((v - (float)h) * 2048.0f);
+        }
+        std::memcpy(&packed[g], hi, 32);
+        std::memcpy(&packed[g + 8], lo, 32);
+    }
+    return s;
+}
+
+// What dad_model_finalize uploads for one conv launch.
+struct PackedOp {
+    std::vector<float> w, bias, rbias;
+};
+// Decides the layer's kernel family (direct-B, split-f16) and produces its packed image.
+inline int pack_op(HostModel* m, ConvOp& op, PackedOp& out) {
+    auto need = [&](const std::string& key) -> const HostTensor* {
+        auto it = m->raw.find(key);
+        return it == m->raw.end() ? nullptr : &it->second;
+    };
+    const HostTensor* w = need(op.name + ".weight");
+    const HostTensor* b = need(op.name + ".bias");
+    if (!w || !b) return fail(DAD_E_KEY, "missing key '%s.weight/.bias'", op.name.c_str());
+    // wide-group layers (op.kc == 8) use the direct-B kernel in either arithmetic: 16-channel
+    // granules, whole 32-channel chunks, 5-tap stride-1 only (else the LDS-staged wide kernel)
+    const int cin_all = op.cin0 + op.cin1;
+    op.bdir = op.kc == 8 && op.kind == CONV_K5 &&
+              (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
+    const int pack_g = op.bdir ? 16 : op.kc;
+    op.ride = !op.rname.empty() && !op.bdir && m->precision == DAD_PREC_FP32;
+    if (op.kind == CONV_UP) {
+        out.w = pack_convT(*w, op.cin_pad, pack_g);
+    } else {
+        const int wt = op.wtaps();
+        out.w.assign((size_t)op.cin_pad * wt * (size_t)op.M, 0.0f);
+        pack_conv_into(out.w, *w, wt, 0, pack_g);
+        if (op.ride) {
+            const HostTensor* rw = need(op.rname + ".weight");
+            const HostTensor* rb = need(op.rname + ".bias");
+            if (!rw || !rb) return fail(DAD_E_KEY, "missing key '%s.weight/.bias'", op.rname.c_str());
+            pack_conv_into(out.w, *rw, wt, op.taps, pack_g);
+            out.rbias = rb->data;
+        }
+    }
+    // split-f16 operands where the kernels exist for every tile this layer may get: 16-channel
+    // granules, and for the strided / transposed convs (no general staging path) whole
+    // 64-channel chunks
+    op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
+            (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
+             (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
+              ((op.cin0 & 63) == 0 && (cin_all & 63) == 0)));
+    op.c1 = 1.0f; op.c2 = 0.0f;
+    if (op.x3) {
+        const int sh = split_f16_image(out.w);
+        op.c1 = std::ldexp(1.0f, -sh);
+        op.c2 = std::ldexp(1.0f, -sh - 11);
+    }
+    out.bias = b->data;
+    if (op.kind == CONV_UP) out.bias.insert(out.bias.end(), b->data.begin(), b->data.end());
+    return DAD_OK;
+}
+
+// ------------------------------------------------------------------------- tile choice
+// Hard constraints: the tile holds whole GroupNorm groups (BM % (C/8) == 0) and whole samples
+// (BN % L == 0), BM divides the columns (each phase half for the transposed conv), the K chunk
+// matches the packed weights.  Preference: enough blocks to cover the 256 CUs; when tiles are
+// scarce, trade tile size for split-K depth.
+inline bool tile_valid(const ConvOp& op, int cfg) {
+    const TileCfg& t = kTiles[cfg];
+    const int Mrows = op.kind == CONV_UP ? op.M / 2 : op.M;
+    const int cpg = op.norm.empty() ? 1 : op.cout / 8;
+    if ((t.KC == 8) != (op.kc == 8)) return false;
+    if (Mrows % t.BM != 0) return false;
+    if (!op.norm.empty() && (t.BM % cpg != 0)) return false;
+    if (t.BN % op.Lout != 0) return false;
+    const int nthreads = 64 * (t.BM / 32) * (t.BN / 32) * t.SK;
+    const int f4pl = t.BM * t.BN / 4 / nthreads;
+    if (!op.norm.empty() && op.Lout * cpg / 4 < f4pl) return false;   // >= 1 lane per (group, sample)
+    return true;
+}
+inline int choose_tile(const HostModel& m, const ConvOp& op, int batch) {
+    auto valid = [&](int cfg) { return tile_valid(op, cfg); };
+    auto blocks = [&](int cfg) {
+        const TileCfg& t = kTiles[cfg];
+        const int spt = t.BN / op.Lout;
+        return (long)((batch + spt - 1) / spt) * (op.M / t.BM);
+    };
+    if (op.kc == 8) return valid(3) ? 3 : -1;
+    if (m.force_tile >= 0 && m.force_tile < kNumTiles && valid(m.force_tile)) return m.force_tile;
+    if (valid(2) && blocks(2) >= 512) return 2;          // plentiful work: big tile
+    if (valid(1) && blocks(1) >= 224) return 1;
+    if (valid(0)) return 0;
+    if (valid(1)) return 1;
+    if (valid(2)) return 2;
+    if (valid(4)) return 4;
+    return -1;
+}
+
+// Per-sample slot shifts of the X stage (conv_gemm.hpp, "Activation rows in LDS and bank
+// conflicts").  Depth-first over the samples of a block tile: d(s) in [0, 16) such that in every
+// 32-row wave tile both 16-lane groups of ds_read_b128 see 16 distinct slots, and no sample is
+// pushed onto its neighbour's real rows (d(s) - d(s+1) <= pad * slots-per-row).  Returns 0 (plain
+// layout — correct, just slower) when L >= 32, when there is no halo, or when nothing is found.
+inline uint64_t find_xswz(HostModel& m, int L, int stride, int pad, int kp4, int BN) {
+    if (L >= 32 || pad == 0 || BN / L > 16) return 0;
+    const std::vector<int> key{L, stride, pad, kp4, BN};
+    auto it = m.xswz_cache.find(key);
+    if (it != m.xswz_cache.end()) return it->second;
+    static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int S = BN / L, seg = L * stride + 2 * pad, per = 32 / L;
+    std::vector<int> d(S, 0);
+    // conflicts among the lanes whose samples are already placed (samples < upto)
+    auto ok_prefix = [&](int upto) {
+        for (int tn = 0; tn * per < upto; ++tn)
+            for (const auto& g : groups) {
+                unsigned seen = 0;
+                for (int lane : g) {
+                    const int n = tn * 32 + lane, sm = n / L, l = n % L;
+                    if (sm >= upto) continue;
+                    const unsigned bit = 1u << (((sm * seg + l * stride) * kp4 + d[sm]) & 15);
+                    if (seen & bit) return false;
+                    seen |= bit;
+                }
+            }
+        return true;
+    };
+    long budget = 300000;                           // node budget: the search is a one-off per shape
+    std::function<bool(int)> place = [&](int sm) -> bool {
+        if (sm == S) return true;
+        for (int v = 0; v < 16; ++v) {
+            if (--budget < 0) return false;
+            if (sm > 0 && d[sm - 1] - v > pad * kp4) continue;
+            d[sm] = v;
+            if (ok_prefix(sm + 1) && place(sm + 1)) return true;
+        }
+        d[sm] = 0;
+        return false;
+    };
+    uint64_t packed = 0;
+    if (place(0))
+        for (int sm = 0; sm < S; ++sm) packed |= (uint64_t)d[sm] << (4 * sm);
+    m.xswz_cache[key] = packed;
+    return packed;
+}
+
+// Grid-level split-K: when a layer has too few output tiles to cover the chip (small batches;
+// the deepest levels of the wide nets), several blocks share a tile and split its K chunks.
+struct SplitPlan { int kslices, chunks_per_slice; long slab_floats; };
+inline SplitPlan plan_split(const HostModel& m, const ConvOp& op, int cfg, int batch) {
+    const TileCfg& t = kTiles[cfg];
+    const int spt = t.BN / op.Lout;
+    const long tiles = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    const int nchunks = (op.cin0 + op.cin1 + kc - 1) / kc;      // chunks holding real channels
+    SplitPlan sp{1, nchunks, 0};
+    if (!m.split_enabled) return sp;
+    if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
+    int want = (int)((m.split_target + tiles - 1) / tiles);
+    if (want > nchunks) want = nchunks;
+    if (want < 2) return sp;
+    sp.chunks_per_slice = (nchunks + want - 1) / want;
+    sp.kslices = (nchunks + sp.chunks_per_slice - 1) / sp.chunks_per_slice;
+    sp.slab_floats = tiles * sp.kslices * (long)t.BN * t.BM;
+    return sp;
+}
+
+// floats of split-K scratch a batch needs (max over layers)
+inline long slab_floats_for(const HostModel& m, int batch) {
+    long best = 0;
+    for (const ConvOp& op : m.plan.convs) {
+        const int cfg = choose_tile(m, op, batch);
+        if (cfg < 0) continue;
+        best = std::max(best, plan_split(m, op, cfg, batch).slab_floats);
+    }
+    return best;
+}
+
+inline size_t workspace_bytes(const HostModel& m, int batch) {
+    return ((size_t)m.plan.floats_per_sample * (size_t)batch + (size_t)slab_floats_for(m, batch)) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------- launch geometry
+// Everything a conv-GEMM launch needs besides pointers, decided on the host and checked here
+// (operand shapes against what the kernel and its grid assume) before anything reaches the GPU.
+struct LaunchGeom {
+    int cfg = -1;            // index into kTiles
+    int kc = 0;              // K chunk of the selected kernel instantiation
+    bool ragged = false;     // general staging path (first layer, narrow nets)
+    int threads = 0;
+    size_t lds_bytes = 0;
+    int ntiles_n = 0, mtiles = 0;
+    unsigned gx = 1, gy = 1, gz = 1;
+    int xcd_gn = 0, xcd_mts = 0, xcd_ntn = 0;
+    bool fused = false;      // the residual conv rides in this launch
+    SplitPlan split{1, 0, 0};
+    uint64_t xswz = 0;
+};
+
+// Does the residual conv ride in `op`'s launch at this batch?  (Needs the whole K in one block
+// and the sixth tap's weight rows in LDS.)
+inline bool fused_at(const HostModel& m, const ConvOp& op, int batch) {
+    if (!op.ride || !m.fuse_residual) return false;
+    const int cfg = choose_tile(m, op, batch);
+    if (cfg < 0) return false;
+    const TileCfg& t = kTiles[cfg];
+    if (t.KC < 16 || plan_split(m, op, cfg, batch).kslices != 1) return false;
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    return dad::conv_lds_floats(t.BM, t.BN, kc, op.taps, op.Lin, op.Lout, t.SK, false, op.taps + 1) *
+               sizeof(float) <= dad::kLdsBytes;
+}
+
+inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g) {
+    if ((long)batch * op.Lout * op.M >= (1L << 31) ||
+        (long)batch * op.Lin * (op.cin0 + op.cin1) >= (1L << 31))
+        return fail(DAD_E_INVALID, "batch %d too large: a layer's activation tensor exceeds 2^31 elements", batch);
+    g.cfg = choose_tile(m, op, batch);
+    if (g.cfg < 0)
+        return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
+                    op.name.c_str(), op.M, op.cout / 8, op.Lout);
+    const TileCfg& t = kTiles[g.cfg];
+    g.kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    const int cin = op.cin0 + op.cin1;
+    g.ragged = (op.cin0 & 3) != 0 || (op.cin1 & 3) != 0 || op.cin0 % g.kc != 0 || cin % g.kc != 0;
+    if (g.ragged && !(op.stride == 1 && (op.taps == 5 || op.taps == 1)))
+        return fail(DAD_E_INVALID, "channel count %d+%d needs the general staging path, which exists "
+                    "for stride-1 5-tap and 1x1 convs only", op.cin0, op.cin1);
+    if (op.bdir && g.ragged)
+        return fail(DAD_E_INVALID, "the direct-B kernel needs whole 32-channel chunks (%d+%d)", op.cin0, op.cin1);
+    if (op.bdir && !(t.KC == 8 && op.taps == 5 && op.stride == 1))
+        return fail(DAD_E_INVALID, "no direct-B kernel for tile %d taps=%d stride=%d", g.cfg, op.taps, op.stride);
+    if (op.x3 && !op.bdir && t.KC < 16)
+        return fail(DAD_E_INVALID, "no split-f16 kernel for tile %d taps=%d stride=%d", g.cfg, op.taps, op.stride);
+    g.fused = fused_at(m, op, batch);
+    if (g.fused && (op.x3 || op.bdir || op.taps != 5 || op.stride != 1))
+        return fail(DAD_E_INVALID, "no fused-residual kernel for %s on tile %d", op.name.c_str(), g.cfg);
+    if (op.cin_pad % g.kc != 0 && !g.ragged)
+        return fail(DAD_E_INVALID, "%s: padded channel count %d is not a multiple of the K chunk %d",
+                    op.name.c_str(), op.cin_pad, g.kc);
+    g.threads = 64 * (t.BM / 32) * (t.BN / 32) * t.SK;
+    g.lds_bytes = dad::conv_lds_floats(t.BM, t.BN, g.kc, op.taps, op.Lin, op.Lout, t.SK, op.bdir,
+                                       op.taps + (g.fused ? 1 : 0)) * sizeof(float);
+    if (g.lds_bytes > dad::kLdsBytes)
+        return fail(DAD_E_INVALID, "%s: tile %d needs %zu bytes of LDS", op.name.c_str(), g.cfg, g.lds_bytes);
+    const int spt = t.BN / op.Lout;
+    g.ntiles_n = (batch + spt - 1) / spt;
+    g.mtiles = op.M / t.BM;
+    if (g.ntiles_n > 65535) return fail(DAD_E_INVALID, "batch too large for one launch (%d N tiles)", g.ntiles_n);
+    g.split = plan_split(m, op, g.cfg, batch);
+    if (g.split.kslices > 1 && (long)g.mtiles * g.ntiles_n > kMaxSplitTiles)
+        return fail(DAD_E_INVALID, "%s: %ld tiles exceed the split-K ticket table", op.name.c_str(),
+                    (long)g.mtiles * g.ntiles_n);
+    // XCD-aware tile order when every XCD gets the same whole rectangle of tiles: choose the
+    // gm x gn arrangement of the 8 XCDs that minimises  gn * (weight bytes) + gm * (activation bytes)
+    const int MT = g.mtiles, NTn = g.ntiles_n;
+    g.gx = (unsigned)g.split.kslices; g.gy = (unsigned)MT; g.gz = (unsigned)NTn;
+    g.xcd_gn = 0;
+    if (m.xcd_order && g.split.kslices == 1 && (MT & (MT - 1)) == 0 && (long)MT * NTn <= 65535 &&
+        ((long)MT * NTn) % 8 == 0) {
+        const double wbytes = (double)op.M * op.taps * cin;
+        const double xbytes = (double)batch * op.Lin * cin;
+        double best = -1;
+        for (int gm = 1; gm <= 8; gm *= 2) {
+            const int gn = 8 / gm;
+            if (MT % gm != 0 || NTn % gn != 0) continue;
+            const double cost = gn * wbytes + gm * xbytes;
+            if (best < 0 || cost < best) {
+                best = cost;
+                g.xcd_gn = gn; g.xcd_mts = ilog2(MT / gm); g.xcd_ntn = NTn / gn;
+            }
+        }
+        if (g.xcd_gn > 0) { g.gy = (unsigned)(MT * NTn); g.gz = 1; }
+    }
+    g.xswz = m.xswz_enabled ? find_xswz(m, op.Lout, op.stride, op.taps / 2, (g.kc + 4) / 4, t.BN) : 0;
+    return DAD_OK;
+}
+
+// Bytes the parameter arena must hold: packed weights, norms, tables, time-MLP weights, flags.
+inline size_t arena_bytes_needed(const HostModel& m) {
+    const dad_cfg& c = m.cfg;
+    size_t floats = 0, allocs = 0;
+    auto add = [&](size_t n) { floats += n + 64; ++allocs; };
+    for (const ConvOp& op : m.plan.convs) {
+        add((size_t)op.cin_pad * (op.taps + (op.rname.empty() ? 0 : 1)) * op.M);
+        add(op.M);
+        if (!op.rname.empty()) add(op.M);
+        if (!op.norm.empty()) { add(op.cout); add(op.cout); }
+        if (op.temb_off >= 0) { add((size_t)op.cout * c.time_dim); add(op.cout); }
+    }
+    add((size_t)c.transition_dim * c.dim); add(c.transition_dim);
+    const size_t T = c.n_timesteps;
+    add(T * c.dim); add(T * 4 * c.time_dim); add(T * c.time_dim);
+    add(T * std::max(1, m.plan.temb_width));
+    add((size_t)4 * c.time_dim * c.dim); add(4 * c.time_dim);
+    add((size_t)c.time_dim * 4 * c.time_dim); add(c.time_dim);
+    return floats * sizeof(float) + allocs * 256 + kMaxSplitTiles * sizeof(unsigned) + (1 << 16);
+}
+
+// SinusoidalPosEmb (temporal_unet.py:27-31) for every t in [0, T): fp32, in the reference's
+// operation order (frequency = exp(j * -ln(1e4)/(half-1)) in fp32, argument = t * frequency).
+inline std::vector<float> sinusoid_table(int T, int dim) {
+    std::vector<float> emb((size_t)T * dim);
+    const int half = dim / 2;
+    const float scale = (float)(-(std::log(10000.0) / (half - 1)));
+    for (int t = 0; t < T; ++t)
+        for (int j = 0; j < half; ++j) {
+            const float f = std::exp((float)j * scale);
+            const float arg = (float)t * f;
+            emb[(size_t)t * dim + j] = std::sin(arg);
+            emb[(size_t)t * dim + half + j] = std::cos(arg);
+        }
+    return emb;
+}
+
+}  // namespace dadhost

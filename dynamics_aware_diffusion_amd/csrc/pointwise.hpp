@@ -248,6 +248,14 @@ __global__ __launch_bounds__(64 * KP) void project_kernel(const ProjParams p) {
     }
 }
 
+// y = Mish(x) through the conv epilogue's device function (mish_fast_f32) — dad_debug_mish: lets a
+// test push torch.nn.Mish's golden grid (|x| > 20, -100, ...) through the arithmetic the fused
+// epilogue runs, without having to construct a network around it.
+__global__ void mish_probe_kernel(const float* in, float* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mish_fast_f32(in[i]);
+}
+
 // ------------------------------------------------------------- time-embedding tables
 // out[t][m] = b[m] + sum_k W[m][k] * f(in[t][k]),  f = Mish when mish_in (the reference's
 // nn.Sequential(Mish, Linear) / Linear -> Mish -> Linear chains), one thread per output.

@@ -108,7 +108,10 @@ class GuidedPolicy(nn.Module):
         diff._check_step(n_steps - 1)
         eng = diff._engine(device)
         philox = diff.sampler_rng == "philox"
-        graph = bool(diff.use_graph) and not self._guided()
+        # the replayed-graph path needs persistent (address-stable) buffers; it is taken only for
+        # the fused loop below, so decide it before anything is allocated
+        _, rest_probe = self._split_conditions(conditions)
+        graph = bool(diff.use_graph) and not self._guided() and not rest_probe
         if philox:
             x = eng.persistent("x", shape) if graph else \
                 torch.empty(shape, device=device, dtype=torch.float32)

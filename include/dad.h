@@ -14,7 +14,10 @@
  *    trajectories use the reference's external layout (batch, horizon, transition_dim).
  *  - all work is enqueued asynchronously on the caller's hipStream_t (passed as void*);
  *    step functions never allocate: the caller passes a workspace of dad_workspace_bytes().
- *  - one dad_model per device per process; functions are thread-compatible, not thread-safe.
+ *  - no process-wide mutable state: every knob (precision, debug hooks, caches, graphs) lives on
+ *    the dad_model; the only statics are the immutable kernel table and a mutex-guarded set of
+ *    devices whose kernels had their LDS limit raised.  One dad_model per device; calls on
+ *    different models may run on different threads (thread-compatible: one thread per model).
  */
 #ifndef DAD_H
 #define DAD_H
@@ -58,7 +61,9 @@ typedef struct dad_cfg {
     int32_t n_levels;                 /* len(dim_mults)                                   */
     int32_t channels[DAD_MAX_LEVELS]; /* dim * dim_mults[i] per level                     */
     int32_t kernel_size;              /* 5 (only value supported)                         */
-    int32_t horizon;                  /* planning horizon H; H / 2^(n_levels-1) >= 1      */
+    int32_t horizon;                  /* planning horizon H: a power of two with
+                                         H / 2^(n_levels-1) >= 4 (the deepest level keeps at
+                                         least 4 positions; else DAD_E_INVALID)              */
     int32_t n_timesteps;              /* length T of the trained schedule                 */
     int32_t predict_epsilon;          /* diffusion.py:192-197                             */
     int32_t clip_denoised;            /* diffusion.py:199-200                             */
@@ -84,6 +89,12 @@ int dad_model_load_weight(dad_model* m, const char* key, const float* data,
 int dad_model_load_schedule(dad_model* m, const float* sqrt_recip, const float* sqrt_recipm1,
                             const float* coef1, const float* coef2, const float* log_var);
 
+/* Optional.  The SinusoidalPosEmb table (temporal_unet.py:19-32) for t = 0 .. n_timesteps-1,
+ * HOST fp32 (n_timesteps, dim), computed by the caller: the Python mirror evaluates the
+ * reference's own torch expression so the table is bit-identical to what the reference computes
+ * on the same host.  Without it dad_model_finalize evaluates the same formula with libm. */
+int dad_model_load_time_embedding(dad_model* m, const float* emb, int32_t n_timesteps, int32_t dim);
+
 /* No reference counterpart (the reference computes in whatever dtype the module holds, fp32 in
  * scripts/evaluate.py): selects the conv arithmetic, DAD_PREC_*.  Takes effect at the next
  * dad_model_finalize (weights are re-packed); a finalized model must be finalized again. */
@@ -94,7 +105,8 @@ int dad_model_set_precision(dad_model* m, int32_t precision);
  * 97-100,155-160 — batch-invariant during sampling) and the launch plan. */
 int dad_model_finalize(dad_model* m, dad_stream_t stream);
 
-/* Bytes of device scratch one call at batch size B needs (activations only). */
+/* Bytes of device scratch one call at batch size B needs: the activation buffers of the launch
+ * plan plus, for batches small enough to use grid-level split-K, the partial-tile slabs. */
 int dad_workspace_bytes(const dad_model* m, int32_t batch, size_t* bytes);
 
 /* Replaces: TemporalUnet.forward(x, t) with one shared timestep t
@@ -173,11 +185,31 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed,
 int dad_profile_enable(dad_model* m, int32_t on);
 int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops);
 
-/* Test / tuning hook: force conv tile configuration `cfg` (0..7, see kTiles in
- * csrc/dad_lib.hip) wherever it is valid for a layer; -1 restores the heuristic; 100+cfg
- * (99 = heuristic tile) additionally disables grid-level split-K.  Results do not depend on
- * these choices beyond fp32 summation order. */
-int dad_debug_set_tile(int32_t cfg);
+/* Test / tuning hooks, all per model (two models in one process do not interact).
+ * dad_debug_set_tile: force conv tile configuration `cfg` (0..7, see kTiles in csrc/host_plan.hpp)
+ * wherever it is valid for a layer; -1 restores the heuristic; 100+cfg (99 = heuristic tile)
+ * additionally disables grid-level split-K.
+ * dad_debug_set_option: "fuse_residual" (the 1x1 residual conv rides in its block's first conv
+ * launch; 0 = always its own launch), "xswz" (LDS slot shifts), "xcd_order" (XCD-aware tile
+ * order), "split_target" (blocks a split-K layer aims for).
+ * Results do not depend on these choices beyond fp32 summation order. */
+int dad_debug_set_tile(dad_model* m, int32_t cfg);
+int dad_debug_set_option(dad_model* m, const char* name, int32_t value);
+
+/* Test hooks for direct comparison against the reference's intermediates (synchronous).
+ * dad_debug_read_table copies row t of a per-timestep table to HOST memory (`capacity` floats
+ * available; the row width is returned in *width_out):
+ *   DAD_TABLE_SINUSOID  SinusoidalPosEmb(t)                      (dim floats;  temporal_unet.py:19-32)
+ *   DAD_TABLE_TIME_MLP  time_mlp(t) = Linear(Mish(Linear(emb)))  (time_dim;    temporal_unet.py:155-160)
+ *   DAD_TABLE_BLOCKS    every block's Linear(Mish(time_mlp(t)))  (sum of C_out over residual
+ *                       blocks, in launch order;                  temporal_unet.py:97-100)
+ * dad_debug_mish applies the conv epilogue's Mish to n device floats. */
+#define DAD_TABLE_SINUSOID 0
+#define DAD_TABLE_TIME_MLP 1
+#define DAD_TABLE_BLOCKS 2
+int dad_debug_read_table(dad_model* m, int32_t which, int32_t t, float* host_out, int32_t capacity,
+                         int32_t* width_out);
+int dad_debug_mish(const float* in, float* out, int64_t n, dad_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,7 @@ def unit_inputs(name: str, ci: int, L: int, B: int, seed: int = 12):
 NETS = {
     "tiny": (4, 2, 32, (1, 2, 4), 20, 3, 0.25),
     "tiny4": (5, 3, 32, (1, 2, 2, 4), 20, 4, 0.25),      # 4 levels, L down to 4, td=8
+    "tiny_td64": (4, 2, 32, (1, 2, 4), 20, 6, 0.25),     # time_dim = 64 (see TIME_DIMS)
     "pointmaze": (4, 2, 128, (1, 2, 4), 100, 0, 0.0),
     "halfcheetah": (17, 6, 256, (1, 4, 8), 1000, 0, 0.0),
     "door": (39, 28, 256, (1, 2, 4, 8), 1000, 0, 0.0),
@@ -107,6 +108,33 @@ LOOP_CASES = [
     ("loop_tiny_linear_T20_B4", "tiny", 20, 20, 4, True, "linear"),
     ("loop_tiny4_T20_B3_cond", "tiny4", 20, 20, 3, True, "cosine"),
     ("loop_pointmaze_T100_B4_cond", "pointmaze", 100, 100, 4, True, "cosine"),
+    ("loop_pointmaze_T100_B1_cond", "pointmaze", 100, 100, 1, True, "cosine"),   # get_action's B=1 plan
+]
+
+# The T=1000 loops of BASELINE configs 4 and 5 (two plans each; the reference takes minutes on
+# them).  Besides the final plans the fixtures hold x after LONG_TRACE iterations, so the CPU
+# suite can pin the oracle on the first and the last few steps instead of all thousand.
+LONG_LOOP_CASES = [
+    ("loop_halfcheetah_T1000_B2", "halfcheetah", 1000, 1000, 2, False, "cosine"),
+    ("loop_door_T1000_B2", "door", 1000, 1000, 2, True, "cosine"),
+]
+LONG_TRACE = (8, 500, 992)
+
+# BASELINE config 3: the README's x_{i-1} = project(denoise(x_i)) — the reference's own
+# p_sample_with_guidance and apply_projection alternated by the harness (the shipped sample_loop
+# never calls apply_projection).  (case, net, T, B, schedule, strength)
+PROJ_LOOP_CASES = [
+    ("loop_pointmaze_T500_B4_proj", "pointmaze", 500, 4, "noise_schedule", 1.0),
+    ("loop_tiny_T20_B3_proj_linear", "tiny", 20, 3, "linear", 0.7),
+]
+
+# GaussianDiffusion / TemporalUnet options off their defaults (diffusion.py:192-200;
+# temporal_unet.py:139,152).  (case, net, T, B, predict_epsilon, clip_denoised)
+OPTION_CASES = [
+    ("opt_tiny_x0_clip", "tiny", 20, 3, False, True),
+    ("opt_tiny_eps_noclip", "tiny", 20, 3, True, False),
+    ("opt_tiny_x0_noclip", "tiny", 20, 3, False, False),
+    ("opt_tinytd_eps_clip", "tiny_td64", 20, 3, True, True),       # time_dim = 64 != dim = 32
 ]
 
 # (case, net, T, B, guide_weight)
@@ -117,6 +145,13 @@ GUIDE_CASES = [
 VALUE_HIDDEN = 16
 
 
+TIME_DIMS = {"tiny_td64": 64}        # nets whose time embedding is wider than `dim`
+
+
+def net_time_dim(net: str):
+    return TIME_DIMS.get(net)
+
+
 def net_dims(net: str):
     od, ad, dim, mults, T, seed, jitter = NETS[net]
     return od, ad, od + ad, dim, mults
@@ -124,7 +159,8 @@ def net_dims(net: str):
 
 def net_weights(net: str) -> "OrderedDict[str, np.ndarray]":
     od, ad, dim, mults, T, seed, jitter = NETS[net]
-    return synth.synth_unet_state(od + ad, dim, mults, seed=seed, affine_jitter=jitter)
+    return synth.synth_unet_state(od + ad, dim, mults, seed=seed, affine_jitter=jitter,
+                                  time_dim=net_time_dim(net))
 
 
 def forward_input(case: str, net: str, B: int) -> np.ndarray:

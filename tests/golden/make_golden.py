@@ -6,7 +6,7 @@ through empty stub packages (the shipped package __init__ files import modules t
 absent from the snapshot — SURVEY.md F3/§8(c)).  Nothing of the reference is copied;
 only inputs (regenerable from ``cases.py``) go in and output arrays come out.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only PREFIX]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only SECTION[,SECTION...]]
 
 Made with torch 2.10.0+rocm7.0 (CPU), numpy 2.2; reference snapshot 2025-10-24.
 """
@@ -87,11 +87,12 @@ def injected_noise(stack: np.ndarray):
         torch.randn, torch.randn_like = real_randn, real_like
 
 
-def build_reference(net: str, T: int, schedule: str = "cosine"):
+def build_reference(net: str, T: int, schedule: str = "cosine", **diffusion_kw):
     od, ad, td, dim, mults = cases.net_dims(net)
-    unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults))
+    unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults), time_dim=cases.net_time_dim(net))
     load_into(unet, cases.net_weights(net))
-    diff = GaussianDiffusion(unet, cases.H, od, ad, n_timesteps=T, beta_schedule=schedule)
+    diff = GaussianDiffusion(unet, cases.H, od, ad, n_timesteps=T, beta_schedule=schedule,
+                             **diffusion_kw)
     return diff.eval()
 
 
@@ -223,6 +224,84 @@ def gen_loops():
         save(case, **out)
 
 
+def gen_long_loops():
+    """BASELINE configs 4 / 5 at T = 1000 (two plans): the reference's own loops, unrolled by the
+    harness exactly as diffusion.py:241-249 / policies.py:134-147 do so that x can be recorded
+    after cases.LONG_TRACE iterations (a manual replay equals the loop bitwise)."""
+    for case, net, T, n_steps, B, conditioned, schedule in cases.LONG_LOOP_CASES:
+        print(f"  long loop {case} ...", flush=True)
+        diff = build_reference(net, T, schedule)
+        noise = cases.loop_noise(case, net, n_steps, B)
+        out = {}
+        x = torch.from_numpy(noise[0]).clone()
+        pol, cond = None, None
+        if conditioned:
+            pol = ref_pol.GuidedPolicy(diff, normalizer=None)
+            cond = {0: torch.from_numpy(cases.loop_condition(case, net))}
+            x = pol.apply_conditions(x, cond)
+        for j, i in enumerate(reversed(range(n_steps))):
+            t = torch.full((B,), i, dtype=torch.long)
+            with injected_noise(noise[1 + j:2 + j]):
+                x = pol.p_sample_with_guidance(x, t, cond) if conditioned else diff.p_sample(x, t)
+            if j + 1 in cases.LONG_TRACE:
+                out[f"x_after_{j + 1}"] = x.numpy().copy()
+            if j % 100 == 99:
+                print(f"    {j + 1}/{n_steps}", flush=True)
+        out["x_final"] = x.numpy()
+        save(case, **out)
+        del diff
+
+
+def gen_proj_loops():
+    """README semantics x_{i-1} = project(denoise(x_i)) with the reference's own
+    p_sample_with_guidance (policies.py:65-112) and apply_projection (policies.py:409-485)."""
+    from oracle.projection import double_integrator
+    A, Bm = double_integrator(0.1)
+    P = ProjectionMatrixBuilder(A, Bm, 4, 2).get_projection_matrix(cases.H)
+    norm = cases.NormalizerStub(4, 2)
+    for case, net, T, B, sched, strength in cases.PROJ_LOOP_CASES:
+        print(f"  projected loop {case} ...", flush=True)
+        diff = build_reference(net, T)
+        pol = ref_pol.DynamicsAwarePolicy(
+            diff, projection_matrix=P, normalizer=norm, state_dim=4, observation_dim=4,
+            action_dim=2, horizon=cases.H, projection_schedule=sched, projection_strength=strength)
+        noise = cases.loop_noise(case, net, T, B)
+        cond = {0: torch.from_numpy(cases.loop_condition(case, net))}
+        x = pol.apply_conditions(torch.from_numpy(noise[0]).clone(), cond)
+        first = None
+        for j, i in enumerate(reversed(range(T))):
+            t = torch.full((B,), i, dtype=torch.long)
+            with injected_noise(noise[1 + j:2 + j]):
+                x = pol.p_sample_with_guidance(x, t, cond)
+            x = pol.apply_projection(x, i)
+            if first is None:
+                first = x.numpy().copy()
+        # the as-shipped loop (no projection) on the same noise, to show the projection matters
+        with injected_noise(noise):
+            plain = pol.sample_loop(batch_size=B, conditions=cond)
+        save(case, x_final=x.numpy(), first_projected=first, x_final_unprojected=plain.numpy())
+
+
+def gen_options():
+    """predict_epsilon / clip_denoised off their defaults (diffusion.py:192-200) and a time
+    embedding wider than dim (temporal_unet.py:154-159)."""
+    for case, net, T, B, pred_eps, clip in cases.OPTION_CASES:
+        print(f"  options {case} ...")
+        diff = build_reference(net, T, predict_epsilon=pred_eps, clip_denoised=clip)
+        noise = cases.loop_noise(case, net, T, B)
+        with injected_noise(noise):
+            x = diff.p_sample_loop((B, cases.H, diff.transition_dim))
+        x0 = torch.from_numpy(noise[0]).clone()
+        t = torch.full((B,), T // 2, dtype=torch.long)
+        with torch.no_grad():
+            eps = diff.model(x0, t)
+            mean, logvar = diff.p_mean_variance(x0.clone(), t)
+        with injected_noise(noise[1:2]):
+            step = diff.p_sample(x0.clone(), t)
+        save(case, x_final=x.numpy(), mid_eps=eps.numpy(), mid_mean=mean.numpy(),
+             mid_logvar=logvar.numpy(), mid_step=step.numpy())
+
+
 class ValueNet(torch.nn.Module):
     def __init__(self, od):
         super().__init__()
@@ -341,7 +420,8 @@ def gen_keys():
 SECTIONS = {
     "keys": gen_keys,
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
-    "forward": gen_forward, "loops": gen_loops, "guidance": gen_guidance,
+    "forward": gen_forward, "loops": gen_loops, "long_loops": gen_long_loops,
+    "proj_loops": gen_proj_loops, "options": gen_options, "guidance": gen_guidance,
     "projection": gen_projection, "glue": gen_glue, "sysid": gen_sysid,
 }
 
@@ -351,7 +431,7 @@ if __name__ == "__main__":
     args = ap.parse_args()
     torch.manual_seed(0)
     for name, fn in SECTIONS.items():
-        if args.only and not name.startswith(args.only):
+        if args.only and name not in args.only.split(","):
             continue
         print(f"[{name}]")
         fn()

@@ -1,0 +1,297 @@
+// host_check.cpp — the host logic of libdad_hip.so (csrc/host_plan.hpp: architecture checks, launch
+// plan, workspace layout, weight packing incl. split-f16 images, tile choice, grid split-K, LDS slot
+// shifts, launch geometry) compiled WITHOUT HIP under -fsanitize=address,undefined and driven over
+// the five architectures of the parity tests plus a deterministic sweep of the fuzz generator's
+// space (tests/fuzz_parity.py).  Besides what the sanitizers catch, every launch is checked against
+// the invariants the kernels assume.  Built and run by tests/test_host_logic.py (CPU suite); GPU
+// sanitizers are not used anywhere.
+#include <cinttypes>
+#include <cstdio>
+#include <random>
+
+#include "../../dynamics_aware_diffusion_amd/csrc/host_plan.hpp"
+
+using namespace dadhost;
+
+static int g_failures = 0;
+#define CHECK(cond, ...)                                                       \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            ++g_failures;                                                      \
+            fprintf(stderr, "CHECK failed %s:%d: %s — ", __FILE__, __LINE__, #cond); \
+            fprintf(stderr, __VA_ARGS__);                                      \
+            fprintf(stderr, "\n");                                             \
+        }                                                                      \
+    } while (0)
+
+struct Arch {
+    const char* name;
+    int td, dim, time_dim, horizon;
+    std::vector<int> mults;
+    bool pack;      // also load synthetic weights and build the packed images
+};
+
+static float synth(uint64_t& state) {       // cheap deterministic values in (-1, 1)
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    return (float)((int64_t)(state >> 33) - (1ll << 30)) / (float)(1ll << 30);
+}
+
+// the conflict condition find_xswz promises, re-checked independently for the shifts it returns
+static bool xswz_conflict_free(uint64_t packed, int L, int stride, int pad, int kp4, int BN) {
+    static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int seg = L * stride + 2 * pad;
+    for (int tn = 0; tn < BN / 32; ++tn)
+        for (const auto& g : groups) {
+            unsigned seen = 0;
+            for (int lane : g) {
+                const int n = tn * 32 + lane, sm = n / L, l = n % L;
+                const int d = (int)((packed >> (4 * sm)) & 15);
+                const unsigned bit = 1u << (((sm * seg + l * stride) * kp4 + d) & 15);
+                if (seen & bit) return false;
+                seen |= bit;
+            }
+        }
+    return true;
+}
+
+static void check_arch(const Arch& a, int precision) {
+    HostModel m;
+    dad_cfg& c = m.cfg;
+    c.transition_dim = a.td; c.dim = a.dim; c.time_dim = a.time_dim;
+    c.n_levels = (int)a.mults.size();
+    for (size_t i = 0; i < a.mults.size(); ++i) c.channels[i] = a.dim * a.mults[i];
+    c.kernel_size = 5; c.horizon = a.horizon; c.n_timesteps = 20;
+    c.predict_epsilon = c.clip_denoised = 1;
+    m.precision = precision;
+    int rc = check_cfg(&c);
+    if (rc != DAD_OK) { printf("  %-14s refused: %s\n", a.name, g_err); return; }
+    rc = build_plan(&m);
+    if (rc != DAD_OK) { printf("  %-14s refused: %s\n", a.name, g_err); return; }
+    const Plan& P = m.plan;
+    CHECK(P.final_act >= 0 && P.final_act < (int)P.bufs.size(), "final_act %d", P.final_act);
+
+    // buffers are disjoint and inside floats_per_sample
+    for (size_t i = 0; i < P.bufs.size(); ++i) {
+        CHECK(P.bufs[i].offset % 4 == 0, "buffer %zu offset %ld not float4 aligned", i, P.bufs[i].offset);
+        CHECK(P.bufs[i].offset + P.bufs[i].per_sample <= P.floats_per_sample, "buffer %zu overruns", i);
+        for (size_t j = i + 1; j < P.bufs.size(); ++j) {
+            const bool apart = P.bufs[i].offset + P.bufs[i].per_sample <= P.bufs[j].offset ||
+                               P.bufs[j].offset + P.bufs[j].per_sample <= P.bufs[i].offset;
+            CHECK(apart, "buffers %zu and %zu overlap", i, j);
+        }
+    }
+    // every op reads / writes buffers big enough for it, and never its own output
+    double flops = 0;
+    int temb_seen = 0;
+    for (const ConvOp& op : P.convs) {
+        auto cap = [&](int id) { return id >= 0 ? P.bufs[id].per_sample : 0L; };
+        const long out_elems = (long)op.cout * (op.kind == CONV_UP ? 2 * op.Lin : op.Lout);
+        CHECK(op.dst >= 0 && cap(op.dst) >= out_elems, "%s: dst too small", op.name.c_str());
+        if (op.src0 >= 0) CHECK(cap(op.src0) >= (long)op.cin0 * op.Lin, "%s: src0 too small", op.name.c_str());
+        if (op.src1 >= 0) CHECK(cap(op.src1) >= (long)op.cin1 * op.Lin, "%s: src1 too small", op.name.c_str());
+        CHECK(op.dst != op.src0 && op.dst != op.src1, "%s: in-place conv", op.name.c_str());
+        if (op.res >= 0) CHECK(op.res != op.dst && cap(op.res) >= out_elems, "%s: residual buffer", op.name.c_str());
+        if (op.rdst >= 0) CHECK(op.rdst != op.dst && op.rdst != op.src0 && op.rdst != op.src1 &&
+                                cap(op.rdst) >= out_elems, "%s: ride buffer", op.name.c_str());
+        if (op.rider_of >= 0)
+            CHECK(op.rider_of < (int)P.convs.size() && P.convs[op.rider_of].rdst == op.dst &&
+                  P.convs[op.rider_of].rname == op.name, "%s: rider link", op.name.c_str());
+        CHECK(op.cin_pad >= op.cin0 + op.cin1, "%s: cin_pad", op.name.c_str());
+        if (op.temb_off >= 0) {
+            CHECK(op.temb_off + op.cout <= P.temb_width, "%s: time table slice", op.name.c_str());
+            temb_seen += op.cout;
+        }
+        flops += op.flops_per_sample;
+    }
+    CHECK(temb_seen == P.temb_width, "time table width %d vs %d", temb_seen, P.temb_width);
+    CHECK(flops > 0, "flops");
+
+    // weights: load synthetic tensors for every expected key, then pack every op
+    if (a.pack) {
+        uint64_t st = 12345;
+        for (const auto& kv : m.expected) {
+            HostTensor& t = m.raw[kv.first];
+            t.shape = kv.second;
+            size_t n = 1;
+            for (int64_t d : kv.second) n *= (size_t)d;
+            t.data.resize(n);
+            for (float& v : t.data) v = synth(st) * 0.05f;
+        }
+        size_t arena = 0;
+        for (ConvOp& op : m.plan.convs) {
+            PackedOp po;
+            rc = pack_op(&m, op, po);
+            CHECK(rc == DAD_OK, "%s: pack_op: %s", op.name.c_str(), g_err);
+            CHECK(po.w.size() == (size_t)op.cin_pad * op.wtaps() * op.M, "%s: packed size", op.name.c_str());
+            CHECK(po.bias.size() == (size_t)op.M, "%s: bias size", op.name.c_str());
+            CHECK(!op.ride || po.rbias.size() == (size_t)op.M, "%s: ride bias size", op.name.c_str());
+            if (op.x3) CHECK(op.c1 > 0 && op.c2 > 0 && std::isfinite(op.c1), "%s: split scales", op.name.c_str());
+            if (!op.x3) {     // the packed image is a permutation of the weights plus zero padding
+                double s_in = 0, s_out = 0;
+                for (float v : m.raw[op.name + ".weight"].data) s_in += v;
+                if (op.ride) for (float v : m.raw[op.rname + ".weight"].data) s_in += v;
+                for (float v : po.w) s_out += v;
+                CHECK(std::fabs(s_in - s_out) <= 1e-6 * (1 + std::fabs(s_in)), "%s: packed checksum", op.name.c_str());
+            }
+            arena += (po.w.size() + po.bias.size() + po.rbias.size()) * sizeof(float) + 3 * 256;
+        }
+        CHECK(arena <= arena_bytes_needed(m), "arena estimate %zu < %zu", arena_bytes_needed(m), arena);
+    } else {
+        for (ConvOp& op : m.plan.convs) {      // kernel-family flags only
+            op.bdir = op.kc == 8 && op.kind == CONV_K5 && (op.cin0 % 32) == 0 &&
+                      ((op.cin0 + op.cin1) % 32) == 0 && op.cin_pad == op.cin0 + op.cin1;
+            op.ride = !op.rname.empty() && !op.bdir && precision == DAD_PREC_FP32;
+            op.x3 = precision == DAD_PREC_F16X3 && (op.bdir || (op.kc == 16 && (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
+                    ((op.cin0 & 63) == 0 && ((op.cin0 + op.cin1) & 63) == 0))));
+        }
+    }
+
+    // launches: every batch size, every forced tile, with and without split-K / fusion
+    const int batches[] = {1, 2, 3, 5, 8, 13, 31, 33, 64, 100, 128, 256, 257, 1024, 2048};
+    long launches = 0;
+    for (int force = -1; force < kNumTiles; ++force)
+        for (int variant = 0; variant < 3; ++variant) {
+            m.force_tile = force;
+            m.split_enabled = variant != 1;
+            m.fuse_residual = variant != 2;
+            for (int B : batches) {
+                const size_t ws = workspace_bytes(m, B);
+                for (const ConvOp& op : m.plan.convs) {
+                    LaunchGeom g;
+                    rc = plan_launch(m, op, B, g);
+                    if (rc != DAD_OK) {
+                        // a refusal must be a message, never a crash; the heuristic (force = -1) must
+                        // always find a launch for an architecture check_cfg accepted
+                        CHECK(force >= 0, "%s B=%d: %s", op.name.c_str(), B, g_err);
+                        continue;
+                    }
+                    ++launches;
+                    const TileCfg& t = kTiles[g.cfg];
+                    CHECK(tile_valid(op, g.cfg), "%s: invalid tile %d", op.name.c_str(), g.cfg);
+                    CHECK(g.threads == 64 * (t.BM / 32) * (t.BN / 32) * t.SK && g.threads <= 1024, "threads %d", g.threads);
+                    CHECK(g.lds_bytes <= dad::kLdsBytes, "%s: LDS %zu", op.name.c_str(), g.lds_bytes);
+                    CHECK(g.kc % (op.x3 ? 16 : 8) == 0 && (g.kc / (op.x3 ? 16 : 8)) % t.SK == 0, "%s: K chunk %d", op.name.c_str(), g.kc);
+                    const long tiles = (long)g.mtiles * g.ntiles_n;
+                    CHECK((long)g.gx * g.gy * g.gz == tiles * g.split.kslices, "%s: grid %u %u %u vs %ld tiles x %d",
+                          op.name.c_str(), g.gx, g.gy, g.gz, tiles, g.split.kslices);
+                    CHECK(g.gy <= 65535 && g.gz <= 65535, "grid dims");
+                    CHECK(g.ntiles_n * (t.BN / op.Lout) >= B, "%s: N tiles do not cover the batch", op.name.c_str());
+                    if (g.split.kslices > 1) {
+                        CHECK(tiles <= kMaxSplitTiles, "ticket table");
+                        CHECK(!g.fused, "%s: ride under grid split-K", op.name.c_str());
+                        const int nchunks = (op.cin0 + op.cin1 + g.kc - 1) / g.kc;
+                        CHECK((g.split.kslices - 1) * g.split.chunks_per_slice < nchunks &&
+                              g.split.kslices * g.split.chunks_per_slice >= nchunks, "%s: K slices", op.name.c_str());
+                        const size_t slab_end = ((size_t)P.floats_per_sample * B + (size_t)g.split.slab_floats) * sizeof(float);
+                        CHECK(slab_end <= ws, "%s B=%d: slab beyond the workspace", op.name.c_str(), B);
+                    }
+                    if (g.xcd_gn > 0) {
+                        const int gm = 8 / g.xcd_gn;
+                        CHECK(g.mtiles % gm == 0 && g.ntiles_n % g.xcd_gn == 0 && (1 << g.xcd_mts) == g.mtiles / gm &&
+                              g.xcd_ntn == g.ntiles_n / g.xcd_gn, "%s: XCD order", op.name.c_str());
+                        // the kernel's decode of a linear block id must be a bijection onto tiles
+                        std::vector<char> hit((size_t)tiles, 0);
+                        for (long wg = 0; wg < tiles; ++wg) {
+                            const int cc = (int)(wg & 7), j = (int)(wg >> 3);
+                            const int im = cc / g.xcd_gn, in = cc - im * g.xcd_gn;
+                            const int mt = (im << g.xcd_mts) + (j & ((1 << g.xcd_mts) - 1));
+                            const int nt = in * g.xcd_ntn + (j >> g.xcd_mts);
+                            CHECK(mt < g.mtiles && nt < g.ntiles_n, "%s: XCD decode out of range", op.name.c_str());
+                            if (mt < g.mtiles && nt < g.ntiles_n) hit[(size_t)mt * g.ntiles_n + nt]++;
+                        }
+                        for (char h : hit) CHECK(h == 1, "%s: XCD decode not a bijection", op.name.c_str());
+                    }
+                    if (g.xswz != 0) {
+                        const int pad = op.taps / 2, kp4 = (g.kc + 4) / 4;
+                        CHECK(xswz_conflict_free(g.xswz, op.Lout, op.stride, pad, kp4, t.BN), "%s: slot shifts conflict", op.name.c_str());
+                        const int S = t.BN / op.Lout;
+                        for (int s = 0; s + 1 < S; ++s) {
+                            const int d0 = (int)((g.xswz >> (4 * s)) & 15), d1 = (int)((g.xswz >> (4 * (s + 1))) & 15);
+                            CHECK(d0 - d1 <= pad * kp4, "%s: shift pushes a sample onto its neighbour", op.name.c_str());
+                        }
+                        // the stage was sized with kXSwzPad floats of slack for shifts of at most 15 slots
+                        CHECK(15 * 4 <= dad::kXSwzPad, "slot shift slack");
+                    }
+                    if (g.fused) CHECK(op.ride && op.taps == 5 && op.stride == 1 && !op.x3 && !op.bdir, "%s: ride", op.name.c_str());
+                }
+            }
+        }
+    printf("  %-14s prec=%d: %zu launches in the plan, %zu buffers, %ld floats/sample, %ld launch geometries checked\n",
+           a.name, precision, P.convs.size(), P.bufs.size(), P.floats_per_sample, launches);
+}
+
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && std::string(argv[1]) == "--quick";
+    std::vector<Arch> archs = {
+        {"tiny", 6, 32, 32, 32, {1, 2, 4}, true},
+        {"tiny4", 8, 32, 32, 32, {1, 2, 2, 4}, true},
+        {"tiny_td64", 6, 32, 64, 32, {1, 2, 4}, true},
+        {"pointmaze", 6, 128, 128, 32, {1, 2, 4}, true},
+        {"halfcheetah", 23, 256, 256, 32, {1, 4, 8}, !quick},
+        {"door", 67, 256, 256, 32, {1, 2, 4, 8}, !quick},
+        {"shrink", 6, 32, 32, 32, {1, 4, 2}, true},
+        {"shrink2", 5, 32, 32, 32, {1, 4, 2, 1}, true},
+        {"single", 3, 32, 32, 32, {1}, true},
+        {"h8", 8, 128, 128, 8, {1, 4}, true},
+        {"h64", 23, 64, 64, 64, {1, 1, 2}, true},
+    };
+    // the fuzz generator's space (tests/fuzz_parity.py), deterministic sweep
+    std::mt19937 rng(7);
+    auto pick = [&](std::initializer_list<int> v) { return *(v.begin() + rng() % v.size()); };
+    std::vector<std::string> names;
+    names.reserve(64);
+    for (int it = 0; it < 40; ++it) {
+        const int dim = pick({32, 64, 128, 256});
+        const int nlev = pick({1, 2, 3, 4});
+        std::vector<int> mults{1};
+        int mx = 1;
+        for (int i = 1; i < nlev; ++i) { mults.push_back(pick({1, 2, 4, 8})); mx = std::max(mx, mults.back()); }
+        const int H = pick({8, 16, 32, 64});
+        const int td = 2 + (int)(rng() % 23);
+        if (mx * dim > 2048) continue;
+        names.push_back("fuzz" + std::to_string(it));
+        archs.push_back({names.back().c_str(), td, dim, dim, H, mults, mx * dim <= 512});
+    }
+    for (const Arch& a : archs)
+        for (int prec : {DAD_PREC_FP32, DAD_PREC_F16X3}) check_arch(a, prec);
+
+    // refusals are messages
+    dad_cfg bad{};
+    bad.transition_dim = 6; bad.dim = 48; bad.time_dim = 48; bad.n_levels = 2;
+    bad.channels[0] = 48; bad.channels[1] = 96; bad.kernel_size = 5; bad.horizon = 32; bad.n_timesteps = 10;
+    CHECK(check_cfg(&bad) == DAD_E_INVALID && g_err[0] != 0, "48 channels accepted");
+    bad.dim = 32; bad.channels[0] = 32; bad.channels[1] = 64; bad.horizon = 4;
+    CHECK(check_cfg(&bad) == DAD_E_INVALID, "horizon 4 with two levels accepted");
+    CHECK(check_cfg(nullptr) == DAD_E_INVALID, "null cfg accepted");
+
+    // split-f16 images: round trip hi + lo * 2^-11 reproduces the scaled weight to 2^-22
+    {
+        std::vector<float> w(64);
+        uint64_t st = 99;
+        for (float& v : w) v = synth(st) * 0.3f;
+        w[5] = 0.0f; w[6] = 1e-8f;
+        std::vector<float> img = w;
+        const int s = split_f16_image(img);
+        for (size_t g = 0; g < w.size(); g += 16)
+            for (int j = 0; j < 16; ++j) {
+                uint16_t hb, lb;
+                std::memcpy(&hb, (const char*)&img[g] + 2 * j, 2);
+                std::memcpy(&lb, (const char*)&img[g + 8] + 2 * j, 2);
+                _Float16 h, l;
+                std::memcpy(&h, &hb, 2); std::memcpy(&l, &lb, 2);
+                const double back = ((double)(float)h + (double)(float)l / 2048.0) * std::ldexp(1.0, -s);
+                CHECK(std::fabs(back - w[g + j]) <= std::ldexp(std::fabs((double)w[g + j]), -21) + 1e-12,
+                      "split image element %zu: %g vs %g", g + j, back, (double)w[g + j]);
+            }
+    }
+    // sinusoid table: shape and a few exact entries
+    {
+        const std::vector<float> e = sinusoid_table(10, 32);
+        CHECK(e.size() == 320 && e[0] == 0.0f && e[16] == 1.0f, "sinusoid table t=0");
+        CHECK(std::fabs(e[32] - std::sin(1.0f)) < 1e-7, "sinusoid table t=1");
+    }
+    if (g_failures) { fprintf(stderr, "%d host-logic checks FAILED\n", g_failures); return 1; }
+    printf("host logic ok\n");
+    return 0;
+}

@@ -29,41 +29,39 @@ def _oracle_eps(net, x, t):
 @pytest.mark.parametrize("tile", list(range(8)))
 def test_every_tile_variant_matches_oracle(tile, dev):
     """Force each (BM, BN, split-K, K-chunk) instantiation wherever it is valid."""
-    from dynamics_aware_diffusion_amd import _engine
     from dynamics_aware_diffusion_amd.utils import synth
-    lib = _engine.load_library()
-    try:
-        lib.dad_debug_set_tile(tile)
-        for net, B in (("tiny", 5), ("pointmaze", 9)):
-            diff = build(net, cases.NETS[net][4], "cosine", dev)
+    for net, B in (("tiny", 5), ("pointmaze", 9)):
+        diff = build(net, cases.NETS[net][4], "cosine", dev)
+        eng = diff._engine(dev)
+        try:
+            eng.debug_set_tile(tile)
             x = torch.from_numpy(synth.normal_like(61, f"tile{tile}.{net}", (B, 32, diff.transition_dim)))
             want = _oracle_eps(net, x, 3)
             got = diff.model(x.to(dev), 3)
             torch.cuda.synchronize()
             assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, (tile, net)
-    finally:
-        lib.dad_debug_set_tile(-1)
+        finally:
+            eng.debug_set_tile(-1)
 
 
 def test_grid_split_k_is_exact_to_rounding_and_deterministic(dev):
     """Small batches split K over several blocks per tile (last-arriver reduction in slice
     order): same answer as the unsplit kernel to fp32 rounding, bit-identical run to run."""
-    from dynamics_aware_diffusion_amd import _engine
     from dynamics_aware_diffusion_amd.utils import synth
-    lib = _engine.load_library()
     diff = build("pointmaze", 100, "cosine", dev)
+    eng = diff._engine(dev)
     for B in (1, 3, 8):
         x = torch.from_numpy(synth.normal_like(65, f"splitk.{B}", (B, 32, 6)))
         want = _oracle_eps("pointmaze", x, 42).numpy()
         xd = x.to(dev)
         try:
-            lib.dad_debug_set_tile(-1)
+            eng.debug_set_tile(-1)
             a = diff.model(xd, 42).cpu().numpy()
             b = diff.model(xd, 42).cpu().numpy()
-            lib.dad_debug_set_tile(99)                   # heuristic tiles, split-K off
+            eng.debug_set_tile(99)                       # heuristic tiles, split-K off
             c = diff.model(xd, 42).cpu().numpy()
         finally:
-            lib.dad_debug_set_tile(-1)
+            eng.debug_set_tile(-1)
         assert np.array_equal(a, b)
         assert max_abs(a, want) <= TOL_STEP and max_abs(c, want) <= TOL_STEP
         assert max_abs(a, c) <= 1e-5
@@ -151,12 +149,12 @@ def test_inkernel_philox_matches_its_oracle(dev):
 def test_philox_sampling_is_sharding_invariant_and_deterministic(dev):
     """Rows depend on (seed, global row) only: an 8-row call equals two 4-row calls at row
     offsets 0 and 4, and a repeat is bit-identical."""
-    from dynamics_aware_diffusion_amd import GuidedPolicy, _engine
+    from dynamics_aware_diffusion_amd import GuidedPolicy
     diff = build("tiny", 20, "cosine", dev)
     diff.sampler_rng, diff.seed = "philox", 4242
-    lib = _engine.load_library()
+    eng = diff._engine(dev)
     try:
-        lib.dad_debug_set_tile(101)                    # tile 1, no grid split-K => same summation order
+        eng.debug_set_tile(101)                        # tile 1, no grid split-K => same summation order
         pol = GuidedPolicy(diff, None)
         cond = {0: torch.from_numpy(cases.loop_condition("inv", "tiny")).to(dev)}
         full = pol.sample_loop(batch_size=8, conditions=cond)
@@ -176,7 +174,7 @@ def test_philox_sampling_is_sharding_invariant_and_deterministic(dev):
         c = diff.p_sample_loop((4, 32, 6), row_offset=4)
         assert torch.equal(b[4:], c) and not torch.equal(a, c)
     finally:
-        lib.dad_debug_set_tile(-1)
+        eng.debug_set_tile(-1)
         diff.sampler_rng = "torch"
 
 
@@ -214,32 +212,83 @@ def test_projection_inside_the_loop_opt_in(dev):
     assert max_abs(want_proj.numpy(), want_plain.numpy()) > 1e-3      # the projection matters
 
 
-def test_full_size_properties_pointmaze_b256(dev):
-    """BASELINE config 2 at full size (batch 256, T=100), through size-independent checks:
-    rows are independent of their batch (rows 0..3 of the 256-row run == a 4-row run),
-    inpainted step 0 is exact, x0-clamping keeps plans bounded, results are deterministic."""
+FULL_SIZE = [
+    # (id, net, T, batch, projected)          BASELINE.json configs 2, 3, 4 and 5 (per-GPU shard)
+    ("cfg2_pointmaze_T100_b256", "pointmaze", 100, 256, False),
+    ("cfg3_pointmaze_T500_b256_proj", "pointmaze", 500, 256, True),
+    ("cfg4_halfcheetah_T1000_b128", "halfcheetah", 1000, 128, False),
+    ("cfg5_door_T1000_b128", "door", 1000, 128, False),
+]
+
+
+@pytest.mark.parametrize("cfg", FULL_SIZE, ids=lambda c: c[0])
+def test_full_size_properties(cfg, dev):
+    """Every BASELINE configuration at its full size, through size-independent checks: rows are
+    independent of their batch (rows 0..3 of the full run == a 4-row run), the inpainted step 0 is
+    exact and x0-clamping keeps plans in [-1, 1] (unprojected loops), results are deterministic,
+    distinct rows are distinct plans."""
     from dynamics_aware_diffusion_amd import GuidedPolicy
-    net, T = "pointmaze", 100
+    from tests.test_hip_parity import _double_integrator_policy
+    name, net, T, B, projected = cfg
     diff = build(net, T, "cosine", dev)
     diff.sampler_rng, diff.seed = "philox", 99
+    td = diff.transition_dim
     try:
-        pol = GuidedPolicy(diff, None)
+        if projected:
+            pol = _double_integrator_policy(diff, "noise_schedule", 1.0, dev, project_during_sampling=True)
+        else:
+            pol = GuidedPolicy(diff, None)
         c = cases.loop_condition("full", net)
         cond = {0: torch.from_numpy(c).to(dev)}
-        big = pol.sample_loop(batch_size=256, conditions=cond)
-        big2 = pol.sample_loop(batch_size=256, conditions=cond)
+        big = pol.sample_loop(batch_size=B, conditions=cond)
+        big2 = pol.sample_loop(batch_size=B, conditions=cond)
         small = pol.sample_loop(batch_size=4, conditions=cond)
         torch.cuda.synchronize()
         assert torch.equal(big, big2)
         assert torch.isfinite(big).all()
-        assert np.array_equal(big[:, 0].cpu().numpy(), np.broadcast_to(c, (256, 6)))
-        assert float(big.abs().max()) <= 1.0 + 1e-3          # last step: sigma = 0, |x0| <= 1
-        # batch 4 and batch 256 may pick different tiles (summation order): fp32 tolerance
+        if not projected:
+            assert np.array_equal(big[:, 0].cpu().numpy(), np.broadcast_to(c, (B, td)))
+            assert float(big.abs().max()) <= 1.0 + 1e-3      # last step: sigma = 0, |x0| <= 1
+        else:
+            # v' = a P v + (1-a) v shrinks the off-subspace part by (1-a) per step: after the last
+            # step (a = sqrt(1 - beta_0) ~ 0.9997) the plans obey x_{t+1} = A x_t + B u_t
+            norm = pol.normalizer
+            xs = big[:, :, :4].double().cpu() * torch.from_numpy(norm.obs_std).double() + torch.from_numpy(norm.obs_mean).double()
+            us = big[:, :, 4:].double().cpu() * torch.from_numpy(norm.action_std).double() + torch.from_numpy(norm.action_mean).double()
+            A, Bm = oproj.double_integrator(0.1)
+            A, Bm = torch.from_numpy(np.asarray(A)).double(), torch.from_numpy(np.asarray(Bm)).double()
+            resid = xs[:, 1:] - (xs[:, :-1] @ A.T + us[:, :-1] @ Bm.T)
+            assert float(resid.abs().max()) <= 5e-3 * max(1.0, float(xs.abs().max()))
+        # batch 4 and the full batch may pick different tiles (summation order): fp32 tolerance
         assert max_abs(big[:4].cpu().numpy(), small.cpu().numpy()) <= TOL_LOOP
         # distinct rows are distinct plans
         assert float((big[1:] - big[:-1]).abs().max()) > 1e-2
     finally:
         diff.sampler_rng = "torch"
+
+
+def test_projection_kernel_beyond_one_wave_of_blocks_at_wide_dims(dev):
+    """dad_project at B > 512 picks four rows per block only when they fit LDS: D = 753
+    (HalfCheetah-sized n = 17, m = 6) must fall back to one row per block and still match."""
+    from dynamics_aware_diffusion_amd._engine import ProjectionState
+    from dynamics_aware_diffusion_amd.utils import synth
+    n, m, H, B = 17, 6, 32, 520
+    D = (H + 1) * n + H * m
+    assert 17 * 4 * D * 4 > 160 * 1024 >= 17 * D * 4
+    rng = np.random.default_rng(3)
+    Q, _ = np.linalg.qr(rng.normal(size=(D, n + H * m)))
+    P = torch.from_numpy((Q @ Q.T).astype(np.float32))
+    stats = [torch.from_numpy(v) for v in (synth.normal_like(5, "wp.om", (n,)),
+                                           1.0 + synth.uniform(5, "wp.os", (n,), 0.5),
+                                           synth.normal_like(5, "wp.am", (m,)),
+                                           1.0 + synth.uniform(5, "wp.as", (m,), 0.5))]
+    x = torch.from_numpy(synth.normal_like(5, "wp.x", (B, H, n + m)))
+    want = oproj.apply_projection(x, P, 0.75, n, n, *stats)
+    st = ProjectionState(P, *stats, n, n, m, dev)
+    xd = x.to(dev).clone()
+    st.apply(xd, 0.75)
+    torch.cuda.synchronize()
+    assert max_abs(xd.cpu().numpy(), want.numpy()) <= 2e-5
 
 
 def test_engine_argument_errors(dev):

@@ -19,6 +19,9 @@ from tests.test_hip_parity import (  # noqa: F401  (collected here under the spl
     test_graph_replay_matches_eager,
     test_value_guidance_vs_reference,
     test_get_action_glue_vs_reference,
+    test_t1000_loops_vs_reference,
+    test_projected_loops_vs_reference,
+    test_diffusion_options_vs_reference,
 )
 from tests.test_hip_extra import (  # noqa: F401
     test_every_tile_variant_matches_oracle,
@@ -27,7 +30,7 @@ from tests.test_hip_extra import (  # noqa: F401
     test_wide_nets_at_a_ragged_multi_tile_batch,
     test_ragged_batches_match_oracle,
     test_philox_sampling_is_sharding_invariant_and_deterministic,
-    test_full_size_properties_pointmaze_b256,
+    test_full_size_properties,
     test_weights_refresh_after_load_state_dict,
     test_assorted_architectures_match_oracle,
     test_batched_get_actions_matches_per_env_oracle,

@@ -73,6 +73,76 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == -1
 
 
+def _pointmaze_cfg():
+    from dynamics_aware_diffusion_amd import _engine
+    cfg = _engine.DadCfg()
+    cfg.transition_dim, cfg.dim, cfg.time_dim, cfg.n_levels = 6, 128, 128, 3
+    for i, ch in enumerate((128, 256, 512)):
+        cfg.channels[i] = ch
+    cfg.kernel_size, cfg.horizon, cfg.n_timesteps = 5, 32, 100
+    cfg.predict_epsilon = cfg.clip_denoised = 1
+    return cfg
+
+
+def test_debug_hooks_are_per_model():
+    """no global state behind the ABI.  Tile / split-K / fusion hooks set on one
+    model leave another model in the same process untouched (checked through the workspace size,
+    which depends on the tile choice and on grid-level split-K — no GPU needed)."""
+    import ctypes as C
+    from dynamics_aware_diffusion_amd import _engine
+    lib = _engine.load_library()
+    cfg = _pointmaze_cfg()
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.dad_model_create(C.byref(cfg), C.byref(a)) == 0
+    assert lib.dad_model_create(C.byref(cfg), C.byref(b)) == 0
+
+    def ws(h, batch):
+        n = C.c_size_t()
+        assert lib.dad_workspace_bytes(h, batch, C.byref(n)) == 0
+        return n.value
+
+    base = ws(b, 1)
+    assert ws(a, 1) == base
+    assert lib.dad_debug_set_tile(a, 99) == 0              # heuristic tiles, grid split-K off
+    assert ws(a, 1) < base                                 # no split-K slabs any more
+    assert ws(b, 1) == base                                # the other model did not notice
+    assert lib.dad_debug_set_option(a, b"split_target", 64) == 0
+    assert lib.dad_debug_set_option(a, b"no_such_option", 1) == -1
+    assert b"no_such_option" in lib.dad_last_error()
+    assert lib.dad_debug_set_tile(a, -1) == 0
+    assert ws(a, 1) < base and ws(b, 1) == base            # split target 64 < 256: smaller slabs
+    assert lib.dad_debug_set_tile(None, 1) == -1
+    # table read-back and the time-embedding upload validate before touching the device
+    buf = (C.c_float * 16)()
+    assert lib.dad_debug_read_table(a, 0, 0, buf, 16, None) == -2          # not finalized
+    assert lib.dad_model_load_time_embedding(a, buf, 7, 128) == -1         # wrong shape
+    assert lib.dad_debug_mish(None, None, 4, None) == -1
+    lib.dad_model_destroy(a)
+    lib.dad_model_destroy(b)
+
+
+def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
+    """the launch planner, packers, split-f16 imaging, tile / split-K choice and
+    LDS slot-shift search compiled host-only with -fsanitize=address,undefined and run over the
+    five architectures plus the fuzz generator's space (tests/sanitize/host_check.cpp).  CPU
+    build only — GPU sanitizers are not available on this pool."""
+    import shutil
+    cxx = shutil.which("amdclang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    assert os.path.exists(cxx) or shutil.which(cxx), "ROCm clang++ not found"
+    exe = tmp_path / "host_check"
+    src = os.path.join(ROOT, "tests", "sanitize", "host_check.cpp")
+    build = subprocess.run([cxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-Wall",
+                            "-Werror", "-o", str(exe), src], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-4000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
+                                  UBSAN_OPTIONS="print_stacktrace=1"))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    assert "host logic ok" in run.stdout
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr
+
+
 def test_precision_names_are_validated_before_any_device_call():
     from dynamics_aware_diffusion_amd import _engine
     assert _engine.PRECISIONS == {"fp32": 0, "f16x3": 1}

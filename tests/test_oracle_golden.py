@@ -97,6 +97,80 @@ def test_sampling_loops(case):
     assert max_abs(step.numpy(), g["first_step"]) <= TOL
 
 
+@pytest.mark.parametrize("case", cases.LONG_LOOP_CASES, ids=lambda c: c[0])
+def test_long_loops_first_and_last_steps(case):
+    """BASELINE configs 4 / 5 (T = 1000): the oracle replays the reference's first 8 and last 8
+    iterations from the recorded states (the whole loop takes the CPU minutes; the GPU test
+    runs all thousand steps against x_final)."""
+    name, net, T, n_steps, B, conditioned, schedule = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    sched = od.schedule_buffers(schedule, T)
+    noise = torch.from_numpy(cases.loop_noise(name, net, n_steps, B))
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net))} if conditioned else None
+
+    def run(x, j0, j1):
+        with torch.no_grad():
+            for j in range(j0, j1):
+                t = torch.full((B,), n_steps - 1 - j, dtype=torch.long)
+                x = od.denoise_step(w, sched, x, t, noise[1 + j], cond)
+        return x
+
+    first, mid, last = cases.LONG_TRACE
+    x = noise[0].clone()
+    if cond is not None:
+        x[:, 0] = cond[0]
+    assert max_abs(run(x, 0, first).numpy(), g[f"x_after_{first}"]) <= 5e-6
+    assert max_abs(run(torch.from_numpy(g[f"x_after_{last}"]), last, n_steps).numpy(), g["x_final"]) <= 5e-6
+    assert f"x_after_{mid}" in g.files
+
+
+@pytest.mark.parametrize("case", cases.PROJ_LOOP_CASES, ids=lambda c: c[0])
+def test_projected_loops(case):
+    """BASELINE config 3: denoise -> project every step, against the reference's own
+    p_sample_with_guidance + apply_projection alternation."""
+    name, net, T, B, psched, strength = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    sched = od.schedule_buffers("cosine", T)
+    noise = torch.from_numpy(cases.loop_noise(name, net, T, B))
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net))}
+    A, Bm = op.double_integrator(0.1)
+    P = op.projection_matrix(A, Bm, cases.H)
+    norm = cases.NormalizerStub(4, 2)
+    stats = [torch.from_numpy(v) for v in (norm.obs_mean, norm.obs_std, norm.action_mean, norm.action_std)]
+
+    def post(x, i):
+        return op.apply_projection(x, P, op.projection_alpha(psched, strength, i, T, sched["betas"]),
+                                   4, 4, *stats)
+
+    trace = []
+    x = od.sample_loop(w, sched, noise, T, cond, post_step=post, trace=trace)
+    assert max_abs(trace[0].numpy(), g["first_projected"]) <= 2e-6
+    assert max_abs(x.numpy(), g["x_final"]) <= 1e-5
+    assert max_abs(g["x_final"], g["x_final_unprojected"]) > 1e-3        # the projection matters
+
+
+@pytest.mark.parametrize("case", cases.OPTION_CASES, ids=lambda c: c[0])
+def test_diffusion_options(case):
+    """predict_epsilon / clip_denoised off their defaults, time_dim != dim (diffusion.py:192-200)."""
+    name, net, T, B, pred_eps, clip = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    sched = od.schedule_buffers("cosine", T)
+    noise = torch.from_numpy(cases.loop_noise(name, net, T, B))
+    x = od.sample_loop(w, sched, noise, T, None, clip_denoised=clip, predict_epsilon=pred_eps)
+    assert max_abs(x.numpy(), g["x_final"]) <= 2e-5
+    t = torch.full((B,), T // 2, dtype=torch.long)
+    with torch.no_grad():
+        mean, logvar, eps = od.p_mean_variance(w, sched, noise[0], t, clip, pred_eps)
+        step = od.denoise_step(w, sched, noise[0].clone(), t, noise[1], None, None, 0.0, clip, pred_eps)
+    assert max_abs(eps.numpy(), g["mid_eps"]) <= TOL
+    assert max_abs(mean.numpy(), g["mid_mean"]) <= 2e-6
+    assert np.array_equal(logvar.numpy(), g["mid_logvar"])
+    assert max_abs(step.numpy(), g["mid_step"]) <= 2e-6
+
+
 def test_truncated_schedule_out_of_range_raises():
     """sampling with more steps than the trained schedule fails in gather."""
     sched = od.schedule_buffers("cosine", 20)
