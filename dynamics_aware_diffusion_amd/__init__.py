@@ -9,7 +9,9 @@ arithmetic runs in ``libdad_hip.so`` (hand-written gfx950 kernels, C ABI in
 from . import dynamics, guides, models
 from .guides import DynamicsAwarePolicy, GuidedPolicy, MPCPolicy, ValueGuidedPolicy
 from .models import GaussianDiffusion, TemporalUnet
+from .utils.checkpoint import infer_architecture, load_checkpoint
 
 __version__ = "0.1.0"
 __all__ = ["models", "guides", "dynamics", "TemporalUnet", "GaussianDiffusion", "GuidedPolicy",
-           "MPCPolicy", "ValueGuidedPolicy", "DynamicsAwarePolicy"]
+           "MPCPolicy", "ValueGuidedPolicy", "DynamicsAwarePolicy", "load_checkpoint",
+           "infer_architecture"]

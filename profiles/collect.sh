@@ -1,45 +1,47 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r01'
-# Pass 1: kernel trace + stats of the default bench command (timings the JSON line must agree with)
-# Pass 2/3: PMC passes, one counter family each (FETCH_SIZE and WRITE_SIZE do not fit one pass,
-#           and gpurun refuses --pmc together with runtime traces).  They profile ONE loop (per-launch
-#           averages do not need more) under a short timeout: rocprofv3 --pmc FETCH_SIZE has hung
-#           intermittently on this pool; ONLY_PMC=1 re-runs just these two passes.
-# Every pass prints a progress line first so the run is never silent.
+#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r02'
+# Pass 1   kernel trace + stats of the bench command (timings the JSON line must agree with).
+# Pass 2-4 counter passes, one counter family each (FETCH_SIZE and WRITE_SIZE do not fit one pass;
+#          gpurun refuses --pmc together with runtime traces), on profiles/pmc_target.py: ONE eager
+#          sampling loop and nothing else — under --pmc every dispatch is serialised (>100 us each).
+# Evidence is never overwritten: every attempt writes <pass>_<HHMMSS>/ and <pass>_<HHMMSS>.log.
+# A pass that hits its timeout leaves its partial CSVs and log in place, gets a <pass>_<HHMMSS>.TIMEOUT
+# note (log tail + file listing), and ENDS the script: nothing further is started on a GPU a killed
+# profiler may have left in an unknown state, and there is no re-run knob.
 set -uo pipefail
-tag="${1:-r01}"
+tag="${1:-r02}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out/profiles_$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-cmd=(python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-alt)
-pmc_cmd=(python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-alt)
-if [ "${ONLY_PMC:-0}" != "1" ]; then
-  echo "[collect] kernel trace"
-  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- "${cmd[@]}" > "$out/trace.log" 2>&1
-fi
-rm -rf "$out/pmc_fetch" "$out/pmc_write"
-echo "[collect] pmc FETCH_SIZE"
-timeout -k 10 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- "${pmc_cmd[@]}" > "$out/pmc_fetch.log" 2>&1
-echo "[collect] pmc WRITE_SIZE"
-timeout -k 10 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- "${pmc_cmd[@]}" > "$out/pmc_write.log" 2>&1
+stamp="$(date +%H%M%S)"
+
+run_pass() {   # name, limit seconds, command...
+  local name="$1" limit="$2"; shift 2
+  local dir="$out/${name}_$stamp" log="$out/${name}_$stamp.log"
+  echo "[collect] $name -> $dir"
+  timeout -k 10 "$limit" "$@" > "$log" 2>&1
+  local rc=$?
+  if [ $rc -ne 0 ]; then
+    { echo "rc=$rc after limit ${limit}s: $*"; echo "--- log tail"; tail -40 "$log"; echo "--- files"; find "$dir" -type f -printf '%s %p\n' 2>/dev/null; } > "$out/${name}_$stamp.TIMEOUT"
+    echo "[collect] $name FAILED rc=$rc (kept $log and $dir); stopping"
+    python3 "$root/profiles/summarize.py" "$out" "$tag" || true
+    exit $rc
+  fi
+}
+
+bench=(python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-configs)
+target=(python3 "$root/profiles/pmc_target.py")
+run_pass trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$stamp" -- "${bench[@]}"
+run_pass pmc_fetch 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$stamp" -- "${target[@]}"
+run_pass pmc_write 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$stamp" -- "${target[@]}"
+run_pass pmc_sq 180 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/pmc_sq_$stamp" -- "${target[@]}"
 # the opt-in split-f16 arithmetic: its own trace and traffic passes
-x3_cmd=(python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-alt --precision f16x3)
-x3_pmc=(python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-alt --precision f16x3)
-rm -rf "$out/x3_fetch" "$out/x3_write"
-if [ "${ONLY_PMC:-0}" != "1" ]; then
-  echo "[collect] kernel trace (f16x3)"
-  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/x3_trace" -- "${x3_cmd[@]}" > "$out/x3_trace.log" 2>&1
-fi
-echo "[collect] pmc FETCH_SIZE (f16x3)"
-timeout -k 10 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/x3_fetch" -- "${x3_pmc[@]}" > "$out/x3_fetch.log" 2>&1
-echo "[collect] pmc WRITE_SIZE (f16x3)"
-timeout -k 10 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/x3_write" -- "${x3_pmc[@]}" > "$out/x3_write.log" 2>&1
-if [ "${ONLY_PMC:-0}" != "1" ]; then
-  echo "[collect] pmc SQ"
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/pmc_sq" -- "${cmd[@]}" > "$out/pmc_sq.log" 2>&1
-  echo "[collect] bench"
-  timeout -k 10 400 python3 "$root/bench.py" --steps 5 --warmup 2 > "$out/bench.json" 2> "$out/bench.err"
-fi
+run_pass x3_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/x3_trace_$stamp" -- "${bench[@]}" --precision f16x3
+run_pass x3_fetch 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/x3_fetch_$stamp" -- "${target[@]}" --precision f16x3
+run_pass x3_write 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/x3_write_$stamp" -- "${target[@]}" --precision f16x3
+echo "[collect] bench"
+timeout -k 10 600 python3 "$root/bench.py" --steps 5 --warmup 2 > "$out/bench_$stamp.json" 2> "$out/bench_$stamp.err"
+cp "$out/bench_$stamp.json" "$out/bench.json"
 python3 "$root/profiles/summarize.py" "$out" "$tag"

@@ -21,12 +21,15 @@ def one(pattern):
     return max(hits, key=os.path.getmtime) if hits else None   # newest pass wins when runs were merged
 
 
-stats = one("trace/**/*_kernel_stats.csv")
+stats = one("trace_*/**/*_kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
 
-summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt"}
-trace = one("trace/**/*_kernel_trace.csv")
+summary = {"tag": tag,
+           "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-configs",
+           "pmc_command": "python3 profiles/pmc_target.py  (one eager sampling loop)",
+           "failed_passes": sorted(os.path.basename(p) for p in glob.glob(os.path.join(src, "*.TIMEOUT")))}
+trace = one("trace_*/**/*_kernel_trace.csv")
 if trace:
     rows = [r for r in csv.DictReader(open(trace)) if "dad::" in r["Kernel_Name"]]
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -36,13 +39,17 @@ if trace:
         a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     summary["kernels_us"] = {k: {"calls": n, "total_us": t, "avg_us": t / n} for k, (n, t) in agg.items()}
     conv = [(n, t) for k, (n, t) in agg.items() if "conv_gemm_f32" in k]
+    steps = sum(n for k, (n, t) in agg.items() if "final_posterior_kernel" in k)     # one per denoise step
     summary["conv_gemm_all_variants"] = {"calls": sum(n for n, _ in conv),
                                          "total_us": sum(t for _, t in conv),
-                                         "avg_us": sum(t for _, t in conv) / max(1, sum(n for n, _ in conv))}
+                                         "avg_us": sum(t for _, t in conv) / max(1, sum(n for n, _ in conv)),
+                                         "launches_per_denoise_step": sum(n for n, _ in conv) / max(1, steps),
+                                         "us_per_denoise_step": sum(t for _, t in conv) / max(1, steps)}
+    summary["all_kernels_us_per_denoise_step"] = sum(t for _, (n, t) in agg.items()) / max(1, steps)
 
 
 def pmc(dirname, counter):
-    f = one(f"{dirname}/**/*_counter_collection.csv")
+    f = one(f"{dirname}_*/**/*_counter_collection.csv")
     if not f:
         return None
     tot, n = collections.defaultdict(float), collections.Counter()
@@ -67,7 +74,7 @@ if fetch and write:
     cur["pointmaze_b256"] = per_launch
     json.dump(cur, open(tpath, "w"), indent=1)
 
-sq = one("pmc_sq/**/*_counter_collection.csv")
+sq = one("pmc_sq_*/**/*_counter_collection.csv")
 if sq:
     tot = collections.defaultdict(float)
     for r in csv.DictReader(open(sq)):
@@ -84,10 +91,10 @@ if sq:
     if tot.get("SQ_LDS_IDX_ACTIVE"):
         summary["lds_bank_conflict_frac"] = tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / tot["SQ_LDS_IDX_ACTIVE"]
 # ---- the split-f16 arithmetic (bench.py --precision f16x3): its own stats table and traffic
-x3stats = one("x3_trace/**/*_kernel_stats.csv")
+x3stats = one("x3_trace_*/**/*_kernel_stats.csv")
 if x3stats:
     shutil.copy(x3stats, os.path.join(here, f"{tag}_kernel_stats_f16x3.csv"))
-x3trace = one("x3_trace/**/*_kernel_trace.csv")
+x3trace = one("x3_trace_*/**/*_kernel_trace.csv")
 if x3trace:
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(x3trace)):

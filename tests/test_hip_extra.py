@@ -482,3 +482,56 @@ def test_large_batch_matches_oracle_rows(dev):
             assert max_abs(y[rows].cpu().numpy(), want) <= TOL_STEP, prec
     finally:
         diff.model.precision = keep
+
+
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks before
+    touching the GPU; they share this box's one GPU (rehearsal mode) and exchange plans and the
+    max-over-ranks time over gloo.  Exercises init_process_group, the gather and the MAX reduce of
+    bench.py itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DAD_BENCH_SHARE_GPU="1", DAD_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "0", "--no-alt", "--no-cpu-baseline", "--no-configs"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 512
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("arch", [(23, 32, (1, 4, 8), 17, 6), (8, 32, (1, 2, 4, 8), 5, 3)],
+                         ids=["mults_1_4_8", "mults_1_2_4_8"])
+def test_checkpoint_round_trip_on_the_device(arch, dev, tmp_path):
+    """load_checkpoint(path) -> sampler on the GPU: the loaded net reproduces the oracle on the
+    checkpoint's weights (raw and EMA), with widths inferred from shapes."""
+    from dynamics_aware_diffusion_amd import load_checkpoint
+    from dynamics_aware_diffusion_amd.utils import synth
+    from tests.test_host_logic import _synthetic_checkpoint
+    td, dim, mults, od, ad = arch
+    ckpt, w, w_ema = _synthetic_checkpoint(td, dim, mults, od, ad, ema_seed=12)
+    path = tmp_path / "model.pt"
+    torch.save(ckpt, path)
+    x = torch.from_numpy(synth.normal_like(69, f"ckpt.{mults}", (3, 32, td)))
+    t = torch.full((3,), 11, dtype=torch.long)
+    outs = []
+    for use_ema, weights in ((False, w), (True, w_ema)):
+        diff = load_checkpoint(path, device=dev, use_ema=use_ema)
+        assert diff.model.dim_mults == mults and diff.betas.device.type == "cuda"
+        with torch.no_grad():
+            want = orc.unet_forward({k: torch.from_numpy(v) for k, v in weights.items()}, x, t)
+        got = diff.model(x.to(dev), 11)
+        torch.cuda.synchronize()
+        assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, use_ema
+        outs.append(got.cpu())
+        plans = diff.p_sample_loop((2, 32, td))                     # and it samples
+        assert torch.isfinite(plans).all()
+    assert float((outs[0] - outs[1]).abs().max()) > 1e-3            # EMA weights are different weights
