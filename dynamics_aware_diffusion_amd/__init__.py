@@ -6,12 +6,12 @@ Drop-in for the sampling path of ``m_diffuser`` (darshangm/dynamics-aware-diffus
 arithmetic runs in ``libdad_hip.so`` (hand-written gfx950 kernels, C ABI in
 ``include/dad.h``).  No CPU fallback exists.
 """
-from . import dynamics, guides, models
+from . import dynamics, guides, losses, models
 from .guides import DynamicsAwarePolicy, GuidedPolicy, MPCPolicy, ValueGuidedPolicy
 from .models import GaussianDiffusion, TemporalUnet
 from .utils.checkpoint import infer_architecture, load_checkpoint
 
 __version__ = "0.1.0"
-__all__ = ["models", "guides", "dynamics", "TemporalUnet", "GaussianDiffusion", "GuidedPolicy",
+__all__ = ["models", "guides", "dynamics", "losses", "TemporalUnet", "GaussianDiffusion", "GuidedPolicy",
            "MPCPolicy", "ValueGuidedPolicy", "DynamicsAwarePolicy", "load_checkpoint",
            "infer_architecture"]

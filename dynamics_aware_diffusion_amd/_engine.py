@@ -61,6 +61,10 @@ ABI = {
     "dad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t)]),
     "dad_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dad_unet_forward_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dad_projection_violation": (C.c_int, [C.POINTER(DadProjectArgs), C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_void_p]),
     "dad_denoise_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.POINTER(DadStepArgs), C.c_int32, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
@@ -264,6 +268,21 @@ class HipEngine:
                 ws.numel() * 4, self._stream()))
         return out
 
+    def unet_forward_rows(self, x: torch.Tensor, t_rows: torch.Tensor) -> torch.Tensor:
+        """eps_theta(x, t) with one timestep per row (the training objective's call); ``t_rows``
+        is range-checked by the caller (``TemporalUnet.forward``)."""
+        B = self._traj(x)
+        t32 = t_rows.to(device=x.device, dtype=torch.int32).contiguous()
+        if t32.numel() != B:
+            raise RuntimeError(f"time must have one entry per row: got {t32.numel()} for batch {B}")
+        out = torch.empty_like(x)
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_unet_forward_rows(
+                self._h, x.data_ptr(), t32.data_ptr(), out.data_ptr(), B, ws.data_ptr(),
+                ws.numel() * 4, self._stream()))
+        return out
+
     def denoise_step(self, x: torch.Tensor, t: int, *, noise: Optional[torch.Tensor] = None,
                      seed: int = 0, row_offset: int = 0, draw: int = 0,
                      cond0: Optional[torch.Tensor] = None,
@@ -389,6 +408,18 @@ class ProjectionState:
         a.state_dim, a.observation_dim, a.action_dim = state_dim, observation_dim, action_dim
         self.args = a
         self.device = dev
+
+    def violation(self, x: torch.Tensor) -> torch.Tensor:
+        """Per-row squared distance from the dynamics-consistent subspace, physical units
+        (ProjectionLoss.compute, losses/__init__.py:161-186, before its mean)."""
+        _require_device(x, "x")
+        out = torch.empty(int(x.shape[0]), dtype=torch.float32, device=x.device)
+        lib = load_library()
+        with torch.cuda.device(self.device):
+            _check(lib, lib.dad_projection_violation(C.byref(self.args), x.data_ptr(), out.data_ptr(),
+                                                     int(x.shape[0]), int(x.shape[1]),
+                                                     torch.cuda.current_stream(self.device).cuda_stream))
+        return out
 
     def apply(self, x: torch.Tensor, alpha: float) -> None:
         _require_device(x, "x")

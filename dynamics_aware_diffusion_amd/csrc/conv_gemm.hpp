@@ -94,6 +94,8 @@ struct ConvParams {
     const float* gamma;  // [M] GroupNorm weight, or nullptr (no norm, no Mish)
     const float* beta;   // [M]
     const float* temb;   // [M] time-embedding projection for this t, or nullptr
+    const int32_t* trow; // per-row timesteps (device, [B]) or nullptr: row b reads temb + trow[b] * temb_stride
+    int32_t temb_stride; //   (training-side forward: diffusion.py:253-290 draws one t per trajectory)
     const float* res;    // [B*Lout][M] residual to add after Mish, or nullptr
     float* dst;          // [B*Lout][M]; interleave mode: [B*2*Lout][M/2]
     int32_t cin0, cin1;  // channels taken from src0 / src1
@@ -516,7 +518,11 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         bias4[k] = ldg4(p.bias + em);                                                            \
         gam4[k] = zero4; bet4[k] = zero4; temb4[k] = zero4; res4[k] = zero4;                     \
         if (has_gn) { gam4[k] = ldg4(p.gamma + em); bet4[k] = ldg4(p.beta + em); }               \
-        if (p.temb != nullptr) temb4[k] = ldg4(p.temb + em);                                     \
+        if (p.temb != nullptr) {                                                                 \
+            const int sb = min(s0 + (erow[k] >> p.lshift), p.B - 1);                             \
+            const long toff = p.trow != nullptr ? (long)p.trow[sb] * p.temb_stride : 0;          \
+            temb4[k] = ldg4(p.temb + toff + em);                                                 \
+        }                                                                                        \
         if (p.res != nullptr && !p.interleave && eoff[k] >= 0) res4[k] = ldg4(p.res + eoff[k]);  \
     }
     DAD_PSTAMP(7);

@@ -193,7 +193,7 @@ int configure_kernels() {
 }
 
 int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int batch, int t,
-             hipStream_t st) {
+             hipStream_t st, const int32_t* trow = nullptr) {
     auto buf = [&](int id) -> float* {
         return id >= 0 ? ws + m->plan.bufs[id].offset * (long)batch : nullptr;
     };
@@ -211,8 +211,10 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.src0 = op.src0 == -2 ? xext : buf(op.src0);
     p.src1 = buf(op.src1);
     p.w = op.d_w; p.bias = op.d_bias; p.gamma = op.d_gamma; p.beta = op.d_beta;
-    p.temb = op.temb_off >= 0 ? m->d_temb_table + (long)t * m->plan.temb_width + op.temb_off : nullptr;
-    p.res = op.res == -2 ? nullptr : buf(op.res);
+    // shared timestep: row t of the table; per-row timesteps: row 0 + trow[b] * stride in the kernel
+    p.temb = op.temb_off >= 0 ? m->d_temb_table + (trow ? 0L : (long)t * m->plan.temb_width) + op.temb_off : nullptr;
+    p.trow = trow; p.temb_stride = m->plan.temb_width;
+    p.res = op.res == -2 ? xext : buf(op.res);       // identity residual of the trajectory itself (td == C)
     p.dst = buf(op.dst);
     p.cin0 = op.cin0; p.cin1 = op.cin1; p.cin_pad = op.cin_pad;
     p.M = op.M; p.cpg = op.norm.empty() ? 0 : op.cout / 8;
@@ -263,7 +265,8 @@ int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
     return DAD_OK;
 }
 
-int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStream_t st) {
+int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStream_t st,
+             const int32_t* trow = nullptr) {
     // Profiling brackets the whole run of conv-GEMM launches of one denoiser evaluation with
     // ONE pair of HIP events on the launch stream (events between individual launches would
     // break the back-to-back dispatch they are meant to time).
@@ -286,7 +289,7 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
         const bool rides = op.rider_of >= 0 && fused_at(*m, convs[op.rider_of], batch);
         if (m->profile) m->prof_flops += op.flops_per_sample * batch;
         if (rides) continue;
-        const int rc = run_conv(m, op, x, ws, batch, t, st);
+        const int rc = run_conv(m, op, x, ws, batch, t, st, trow);
         if (rc != DAD_OK) return rc;
         if (m->profile) ++m->prof_launches;
     }
@@ -334,9 +337,9 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
 }
 
 int run_project(const dad_project_args* pa, float alpha, float* x, int batch, int horizon,
-                hipStream_t st) {
+                hipStream_t st, float* violation = nullptr) {
     if (!pa || !pa->P) return fail(DAD_E_INVALID, "projection arguments missing");
-    if (alpha <= 0.0f) return DAD_OK;                     // policies.py:428-429
+    if (alpha <= 0.0f && !violation) return DAD_OK;       // policies.py:428-429
     {
         const int rc0 = configure_kernels();
         if (rc0 != DAD_OK) return rc0;
@@ -349,6 +352,7 @@ int run_project(const dad_project_args* pa, float alpha, float* x, int batch, in
     p.D = (horizon + 1) * p.n + horizon * p.m;
     p.alpha = alpha;
     p.one_minus_alpha = (float)(1.0 - (double)alpha);
+    p.violation = violation;
     // rows per block: one while the batch fits one wave of blocks (every CU streams P once),
     // four beyond that (P is then re-used by four rows per pass) if four rows fit LDS
     const size_t row_lds = (size_t)(1 + 16) * p.D * sizeof(float);    // a row + its 16 partial sets
@@ -547,6 +551,16 @@ int dad_unet_forward(dad_model* m, const float* x, int32_t t, float* out, int32_
     return run_final(m, nullptr, x, t, batch, nullptr, 1, out, (float*)workspace, st);
 }
 
+int dad_unet_forward_rows(dad_model* m, const float* x, const int32_t* t_rows, float* out, int32_t batch,
+                          void* workspace, size_t workspace_bytes, dad_stream_t stream) {
+    int rc = check_ready(m, batch, 0, workspace_bytes);
+    if (rc != DAD_OK) return rc;
+    if (!x || !out || !workspace || !t_rows) return fail(DAD_E_INVALID, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_unet(m, x, 0, batch, (float*)workspace, st, t_rows)) != DAD_OK) return rc;
+    return run_final(m, nullptr, x, 0, batch, nullptr, 1, out, (float*)workspace, st);
+}
+
 int dad_denoise_step(dad_model* m, float* x, int32_t t, int32_t batch, const dad_step_args* args,
                      int32_t x_out_disabled, void* workspace, size_t workspace_bytes,
                      dad_stream_t stream) {
@@ -562,6 +576,12 @@ int dad_project(const dad_project_args* p, float alpha, float* x, int32_t batch,
                 dad_stream_t stream) {
     if (!x || batch <= 0 || horizon <= 0) return fail(DAD_E_INVALID, "bad argument");
     return run_project(p, alpha, x, batch, horizon, (hipStream_t)stream);
+}
+
+int dad_projection_violation(const dad_project_args* p, const float* x, float* violation, int32_t batch,
+                             int32_t horizon, dad_stream_t stream) {
+    if (!x || !violation || batch <= 0 || horizon <= 0) return fail(DAD_E_INVALID, "bad argument");
+    return run_project(p, 1.0f, const_cast<float*>(x), batch, horizon, (hipStream_t)stream, violation);
 }
 
 int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,

@@ -166,6 +166,8 @@ struct ProjParams {
     float* x;                // (B,H,od+m) in place
     int32_t B, H, n, od, m, D;
     float alpha, one_minus_alpha;
+    float* violation;        // when set: x is left untouched and violation[b] = sum_d (v - vP)_d^2 in
+                             // physical units (losses/__init__.py:161-186, ProjectionLoss.compute)
 };
 
 // One block = RB trajectories, KP waves.  v@P is latency-bound (P = D*D*4 bytes streams through
@@ -217,6 +219,25 @@ __global__ __launch_bounds__(64 * KP) void project_kernel(const ProjParams p) {
         for (int r = 0; r < RB; ++r) part[(kp * RB + r) * D + d] = acc[r];
     }
     __syncthreads();
+    if (p.violation != nullptr) {
+        // ProjectionLoss: squared distance from the dynamics-consistent subspace, summed per row in a
+        // fixed order (wave 0, strided partials then a shuffle tree): deterministic
+        if (threadIdx.x < 64) {
+            for (int r = 0; r < RB; ++r) {
+                float acc = 0.0f;
+                for (int d = threadIdx.x; d < D; d += 64) {
+                    float proj = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < KP; ++q) proj += part[(q * RB + r) * D + d];
+                    const float diff = v[r * D + d] - proj;
+                    acc = fmaf(diff, diff, acc);
+                }
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (threadIdx.x == 0 && b0 + r < p.B) p.violation[b0 + r] = acc;
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < RB * D; e += blockDim.x) {
         const int r = e / D, d = e - r * D;
         const int b = b0 + r;

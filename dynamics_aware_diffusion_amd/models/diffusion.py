@@ -5,7 +5,8 @@ Schedules are computed with the same fp32 torch ops, in the same order, as the r
 (diffusion.py:32-48, 104-128), so the 12 registered buffers are bit-identical and a
 reference checkpoint's buffers load unchanged.  ``p_mean_variance`` / ``p_sample`` /
 ``p_sample_loop`` run on the HIP engine; the per-step tail (x0 prediction, clamp, posterior
-mean, noise, inpainting) is one fused kernel behind ``dad_denoise_step``.
+mean, noise, inpainting) is one fused kernel behind ``dad_denoise_step``.  ``loss`` evaluates the
+training objective forward-only on the same kernels.
 """
 from __future__ import annotations
 
@@ -200,10 +201,26 @@ class GaussianDiffusion(nn.Module):
         return x.clone() if self.use_graph else x
 
     # ------------------------------------------------------------------ training objective
-    def loss(self, x_start, weights=None):
-        raise NotImplementedError(
-            "training (diffusion.py:253-290) is outside the sampling hot path this build "
-            "accelerates (SURVEY.md §8(f) rank 4); the HIP engine has no backward pass")
+    @torch.no_grad()
+    def loss(self, x_start: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The diffusion training objective, FORWARD ONLY (diffusion.py:253-290): t ~ randint per
+        trajectory, noise ~ randn, x_t = q_sample, denoiser on the HIP engine (per-row time
+        embedding), elementwise L1 / L2 against the noise (or x_0), optional weights, mean.
+
+        Same random draws in the same order as the reference (``torch.randint`` then
+        ``torch.randn_like`` on ``x_start``'s device).  The result carries no autograd graph — the
+        engine has no backward pass — so this evaluates a validation /
+        monitoring loss; calling ``.backward()`` on it raises as for any graph-less tensor."""
+        batch = x_start.shape[0]
+        t = torch.randint(0, self.n_timesteps, (batch,), device=x_start.device).long()
+        noise = torch.randn_like(x_start)
+        x_noisy = self.q_sample(x_start, t, noise)
+        model_output = self.model(x_noisy, t)
+        target = noise if self.predict_epsilon else x_start
+        loss = self.loss_fn(model_output, target)
+        if weights is not None:
+            loss = loss * weights
+        return loss.mean()
 
     def forward(self, x, *args, **kwargs):
         return self.loss(x, *args, **kwargs)

@@ -58,8 +58,10 @@ class TemporalUnet(nn.Module):
 
     Same constructor as the reference (temporal_unet.py:135-140).  ``forward(x, time)`` takes
     ``x`` (batch, horizon, transition_dim) and ``time`` (batch,) and returns a tensor like
-    ``x``; all rows must share one timestep, which is what every sampling call site does
-    (diffusion.py:248; guides/policies.py:146).
+    ``x``.  Every sampling call site passes one shared timestep (diffusion.py:248;
+    guides/policies.py:146) — the fast path; rows with different timesteps, as the training
+    objective draws them (diffusion.py:265), take the per-row time-embedding lookup.  Forward
+    only: the engine has no backward pass.
     """
 
     default_precision = "fp32"      # what new instances start with (see ``precision`` below)
@@ -150,9 +152,17 @@ class TemporalUnet(nn.Module):
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, time: Union[int, torch.Tensor]) -> torch.Tensor:
-        t = self.shared_timestep(time)
-        if t >= self._diffusion_opts["n_timesteps"] and self._schedule is None:
+        if isinstance(time, int):
+            lo = hi = time
+        else:
+            lo, hi = int(time.min()), int(time.max())
+        if hi >= self._diffusion_opts["n_timesteps"] and self._schedule is None:
             # bare denoiser: grow the time table on demand
-            self._diffusion_opts["n_timesteps"] = max(2 * self._diffusion_opts["n_timesteps"], t + 1)
+            self._diffusion_opts["n_timesteps"] = max(2 * self._diffusion_opts["n_timesteps"], hi + 1)
+        if lo < 0 or hi >= self._diffusion_opts["n_timesteps"]:
+            raise RuntimeError(f"index {hi if hi >= 0 else lo} is out of bounds for dimension 0 with size "
+                               f"{self._diffusion_opts['n_timesteps']}")
         eng = self.engine(int(x.shape[1]), x.device)
-        return eng.unet_forward(x.contiguous().float(), t)
+        if lo == hi:
+            return eng.unet_forward(x.contiguous().float(), lo)
+        return eng.unet_forward_rows(x.contiguous().float(), time.reshape(-1))

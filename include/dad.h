@@ -114,6 +114,13 @@ int dad_workspace_bytes(const dad_model* m, int32_t batch, size_t* bytes);
 int dad_unet_forward(dad_model* m, const float* x, int32_t t, float* out, int32_t batch,
                      void* workspace, size_t workspace_bytes, dad_stream_t stream);
 
+/* Replaces: TemporalUnet.forward(x, t) with one timestep PER ROW, as the training objective calls
+ * it (GaussianDiffusion.loss, m_diffuser/models/diffusion.py:253-290: t ~ randint per trajectory).
+ * t_rows: (B) int32 on the DEVICE, every entry in [0, n_timesteps) (the caller checks the range:
+ * the library cannot without a device synchronisation).  Forward only — there is no backward. */
+int dad_unet_forward_rows(dad_model* m, const float* x, const int32_t* t_rows, float* out, int32_t batch,
+                          void* workspace, size_t workspace_bytes, dad_stream_t stream);
+
 /* Arguments of one reverse step beyond (x, t). All pointers may be NULL unless noted. */
 typedef struct dad_step_args {
     const float* noise;      /* (B,H,td) injected z; NULL => in-kernel Philox            */
@@ -170,6 +177,13 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
  * alpha (policies.py:358-383 is evaluated by the caller).  x: (B,H,od+m) IN PLACE. */
 int dad_project(const dad_project_args* p, float alpha, float* x, int32_t batch,
                 int32_t horizon, dad_stream_t stream);
+
+/* Replaces: the arithmetic of ProjectionLoss.compute (m_diffuser/losses/__init__.py:161-186):
+ * violation[b] = sum_d (v_b - v_b P)_d^2 with v the de-normalised concatenated trajectory
+ * [s_0..s_{H-1}, s_{H-1}, a_0..a_{H-1}] — the caller divides the sum over rows by B * D.
+ * x (B,H,od+m) is read only; violation: (B) device fp32. */
+int dad_projection_violation(const dad_project_args* p, const float* x, float* violation, int32_t batch,
+                             int32_t horizon, dad_stream_t stream);
 
 /* Replaces: torch.randn(shape) for x_T (diffusion.py:241; policies.py:134) with the
  * library's counter-based generator: element e of global row r gets Philox4x32-10

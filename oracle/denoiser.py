@@ -229,6 +229,28 @@ def sample_loop(w, sched, noise: Tensor, n_timesteps: int,
         return x
 
 
+def training_loss(w, sched: Mapping[str, Tensor], x_start: Tensor, t: Tensor, noise: Tensor,
+                  loss_type: str = "l2", predict_epsilon: bool = True,
+                  weights: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """GaussianDiffusion.loss (diffusion.py:253-290) with its two random draws (t, noise) passed in:
+    x_t = q_sample (diffusion.py:138-157), model on per-row timesteps, elementwise L1 / L2
+    (diffusion.py:130-136), optional weights, mean.  Returns (loss, x_t, model output)."""
+    with torch.no_grad():
+        x_t = _at(sched["sqrt_alphas_cumprod"], t, x_start.dim()) * x_start \
+            + _at(sched["sqrt_one_minus_alphas_cumprod"], t, x_start.dim()) * noise
+        out = unet_forward(w, x_t, t)
+        target = noise if predict_epsilon else x_start
+        if loss_type == "l2":
+            per = (out - target) ** 2
+        elif loss_type == "l1":
+            per = (out - target).abs()
+        else:
+            raise ValueError(f"Unknown loss type: {loss_type}")              # diffusion.py:136
+        if weights is not None:
+            per = per * weights
+        return per.mean(), x_t, out
+
+
 def cast_weights(w: Mapping[str, Tensor], dtype: torch.dtype) -> Dict[str, Tensor]:
     return {k: v.to(dtype) for k, v in w.items()}
 

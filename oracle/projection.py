@@ -97,3 +97,15 @@ def apply_projection(x: Tensor, P: Tensor, alpha: float, state_dim: int, observa
         pad = torch.zeros(Bsz, H, observation_dim - state_dim, dtype=s.dtype)
         s = torch.cat([s, pad], dim=-1)
     return torch.cat([s, a], dim=-1)
+
+
+def projection_violation(x: Tensor, P: Tensor, observation_dim: int, obs_mean: Tensor, obs_std: Tensor,
+                         act_mean: Tensor, act_std: Tensor) -> Tensor:
+    """ProjectionLoss.compute (m_diffuser/losses/__init__.py:93-186): de-normalise, concatenate
+    [s_0..s_{H-1}, s_{H-1}, a_0..a_{H-1}] (ALL observation channels are the state there), project,
+    mean squared distance."""
+    s = x[:, :, :observation_dim] * obs_std + obs_mean
+    a = x[:, :, observation_dim:] * act_std + act_mean
+    ext = torch.cat([s, s[:, -1:, :]], dim=1)
+    v = torch.cat([ext.reshape(x.shape[0], -1), a.reshape(x.shape[0], -1)], dim=1)
+    return torch.mean((v - v @ P) ** 2)

@@ -148,6 +148,28 @@ VALUE_HIDDEN = 16
 TIME_DIMS = {"tiny_td64": 64}        # nets whose time embedding is wider than `dim`
 
 
+# Training objective, forward only (diffusion.py:253-290; losses/__init__.py:37-186).
+# (case, net, T, B, loss_type, predict_epsilon, weighted)
+TRAIN_CASES = [
+    ("train_tiny_l2", "tiny", 20, 6, "l2", True, False),
+    ("train_tiny_l1_w", "tiny", 20, 6, "l1", True, True),
+    ("train_tiny_x0_l2", "tiny", 20, 5, "l2", False, False),
+    ("train_pointmaze_l2", "pointmaze", 100, 9, "l2", True, False),
+]
+
+
+def train_inputs(case: str, net: str, T: int, B: int, weighted: bool):
+    """(x_start, per-row timesteps, noise, weights or None): what loss() draws, made portable."""
+    _, _, td, _, _ = net_dims(net)
+    x0 = np.clip(synth.normal_like(24, case + ".x0", (B, H, td)) * 0.5, -1, 1).astype(np.float32)
+    u = synth.uniform(24, case + ".t", (B,), 1.0)
+    t = np.minimum(((u + 1.0) * 0.5 * T).astype(np.int64), T - 1)
+    t[0], t[-1] = 0, T - 1                                   # both ends of the schedule
+    noise = synth.normal_like(24, case + ".noise", (B, H, td))
+    w = (1.0 + synth.uniform(24, case + ".w", (1, H, td), 0.5)).astype(np.float32) if weighted else None
+    return x0, t, noise, w
+
+
 def net_time_dim(net: str):
     return TIME_DIMS.get(net)
 

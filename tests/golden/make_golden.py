@@ -302,6 +302,42 @@ def gen_options():
              mid_logvar=logvar.numpy(), mid_step=step.numpy())
 
 
+def gen_training():
+    """GaussianDiffusion.loss (diffusion.py:253-290) with its randint / randn_like draws replaced
+    by the portable inputs, the per-row-timestep forward inside it, and ProjectionLoss.compute
+    (losses/__init__.py:161-186)."""
+    from m_diffuser.losses import DiffusionLoss, ProjectionLoss, ComposedLoss
+    from oracle.projection import double_integrator
+    out = {}
+    for case, net, T, B, loss_type, pred_eps, weighted in cases.TRAIN_CASES:
+        print(f"  training {case} ...")
+        diff = build_reference(net, T, loss_type=loss_type, predict_epsilon=pred_eps)
+        x0, t, noise, w = cases.train_inputs(case, net, T, B, weighted)
+        real_randint = torch.randint
+        torch.randint = lambda *a, **k: torch.from_numpy(t).clone()
+        try:
+            with injected_noise(noise[None]), torch.no_grad():
+                loss = diff.loss(torch.from_numpy(x0), None if w is None else torch.from_numpy(w))
+        finally:
+            torch.randint = real_randint
+        with torch.no_grad():
+            xt = diff.q_sample(torch.from_numpy(x0), torch.from_numpy(t), torch.from_numpy(noise))
+            eps = diff.model(xt, torch.from_numpy(t))
+        out[case + ".loss"] = np.float64(loss.item())
+        out[case + ".x_noisy"] = xt.numpy()
+        out[case + ".model_out"] = eps.numpy()
+    # ProjectionLoss on the double-integrator projector + a composed total
+    A, Bm = double_integrator(0.1)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        P = ProjectionMatrixBuilder(A, Bm, 4, 2).get_projection_matrix(cases.H)
+        pl = ProjectionLoss(P, cases.NormalizerStub(4, 2), state_dim=4, action_dim=2, observation_dim=4,
+                            horizon=cases.H, weight=0.1, device="cpu")
+    x = torch.from_numpy(cases.projection_input("train_projloss"))
+    out["projection_loss.compute"] = np.float64(pl.compute({"conditions": x}).item())
+    out["projection_loss.weighted"] = np.float64(pl({"conditions": x}).item())
+    save("training", **out)
+
+
 class ValueNet(torch.nn.Module):
     def __init__(self, od):
         super().__init__()
@@ -421,7 +457,8 @@ SECTIONS = {
     "keys": gen_keys,
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
     "forward": gen_forward, "loops": gen_loops, "long_loops": gen_long_loops,
-    "proj_loops": gen_proj_loops, "options": gen_options, "guidance": gen_guidance,
+    "proj_loops": gen_proj_loops, "options": gen_options, "training": gen_training,
+    "guidance": gen_guidance,
     "projection": gen_projection, "glue": gen_glue, "sysid": gen_sysid,
 }
 

@@ -316,6 +316,58 @@ def test_epilogue_mish_vs_reference(dev):
     assert np.array_equal(y[big], g["mish_in"][big])                     # softplus threshold: identity
 
 
+@pytest.mark.parametrize("case", cases.TRAIN_CASES, ids=lambda c: c[0])
+def test_training_objective_forward_vs_reference(case, dev):
+    """GaussianDiffusion.loss evaluated forward-only on the HIP kernels — the
+    denoiser with one timestep PER ROW — against the reference's loss on the same draws."""
+    name, net, T, B, loss_type, pred_eps, weighted = case
+    g = golden("training")
+    diff = build(net, T, "cosine", dev, loss_type=loss_type, predict_epsilon=pred_eps)
+    x0, t, noise, wts = cases.train_inputs(name, net, T, B, weighted)
+    tt = torch.from_numpy(t).to(dev)
+    xt = diff.q_sample(torch.from_numpy(x0).to(dev), tt, torch.from_numpy(noise).to(dev))
+    assert max_abs(xt.cpu().numpy(), g[name + ".x_noisy"]) <= 1e-6
+    out = diff.model(torch.from_numpy(g[name + ".x_noisy"]).to(dev), tt)
+    torch.cuda.synchronize()
+    err = max_abs(out.cpu().numpy(), g[name + ".model_out"])
+    real_randint = torch.randint
+    torch.randint = lambda *a, **k: tt.clone()
+    try:
+        with injected_noise(noise[None], dev):
+            loss = diff.loss(torch.from_numpy(x0).to(dev), None if wts is None else torch.from_numpy(wts).to(dev))
+    finally:
+        torch.randint = real_randint
+    want = float(g[name + ".loss"])
+    print(f"{name}: per-row forward {err:.2e}, loss {float(loss):.7f} vs {want:.7f}")
+    assert err <= TOL_STEP
+    assert abs(float(loss) - want) <= 2e-6 * max(1.0, abs(want))
+    assert loss.requires_grad is False                       # forward only: no autograd graph
+    with pytest.raises(RuntimeError):
+        diff.model(xt, torch.full((B,), T, device=dev, dtype=torch.long))      # beyond the schedule
+
+
+def test_projection_and_composed_losses_vs_reference(dev):
+    from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder, double_integrator
+    from dynamics_aware_diffusion_amd.losses import ComposedLoss, DiffusionLoss, ProjectionLoss
+    g = golden("training")
+    A, Bm = double_integrator(0.1)
+    P = ProjectionMatrixBuilder(A, Bm, 4, 2).get_projection_matrix(cases.H)
+    pl = ProjectionLoss(P, cases.NormalizerStub(4, 2), state_dim=4, action_dim=2, observation_dim=4,
+                        horizon=cases.H, weight=0.1, device=dev)
+    x = torch.from_numpy(cases.projection_input("train_projloss")).to(dev)
+    batch = {"conditions": x}
+    keep = x.clone()
+    v = float(pl.compute(batch))
+    assert torch.equal(x, keep)                              # read only
+    assert abs(v - float(g["projection_loss.compute"])) <= 2e-5 * float(g["projection_loss.compute"])
+    assert abs(float(pl(batch)) - float(g["projection_loss.weighted"])) <= 2e-5 * float(g["projection_loss.weighted"])
+    diff = build("tiny", 20, "cosine", dev)
+    total, parts = ComposedLoss([DiffusionLoss(diff, weight=1.0), pl])(batch)
+    assert set(parts) == {"diffusion", "projection", "total"}
+    assert abs(parts["total"] - float(total)) <= 1e-6 and abs(parts["projection"] - 0.1 * v) <= 1e-6
+    assert np.isfinite(parts["diffusion"]) and parts["diffusion"] > 0
+
+
 def test_graph_replay_matches_eager(dev):
     name, net, T, n_steps, B, conditioned, schedule = cases.LOOP_CASES[1]
     diff = build(net, T, schedule, dev)

@@ -22,6 +22,7 @@ from tests.test_hip_parity import (  # noqa: F401  (collected here under the spl
     test_t1000_loops_vs_reference,
     test_projected_loops_vs_reference,
     test_diffusion_options_vs_reference,
+    test_training_objective_forward_vs_reference,
 )
 from tests.test_hip_extra import (  # noqa: F401
     test_every_tile_variant_matches_oracle,

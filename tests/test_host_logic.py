@@ -213,7 +213,7 @@ def test_diffusion_attributes_and_errors():
     assert mean.shape == x0.shape and logvar.shape == (3, 1, 1)
     with pytest.raises(RuntimeError):                    # gather out of range, like the reference
         d.q_sample(x0, torch.tensor([0, 5, 50]), z)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # forward-only loss runs on the engine
         d.loss(x0)
 
 

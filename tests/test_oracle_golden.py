@@ -171,6 +171,33 @@ def test_diffusion_options(case):
     assert max_abs(step.numpy(), g["mid_step"]) <= 2e-6
 
 
+@pytest.mark.parametrize("case", cases.TRAIN_CASES, ids=lambda c: c[0])
+def test_training_objective(case):
+    """GaussianDiffusion.loss forward (per-row timesteps) and ProjectionLoss against the reference."""
+    name, net, T, B, loss_type, pred_eps, weighted = case
+    g = golden("training")
+    x0, t, noise, wts = cases.train_inputs(name, net, T, B, weighted)
+    loss, xt, out = od.training_loss(net_weights_torch(net), od.schedule_buffers("cosine", T),
+                                     torch.from_numpy(x0), torch.from_numpy(t), torch.from_numpy(noise),
+                                     loss_type, pred_eps, None if wts is None else torch.from_numpy(wts))
+    assert np.array_equal(xt.numpy(), g[name + ".x_noisy"])
+    assert max_abs(out.numpy(), g[name + ".model_out"]) <= TOL
+    assert abs(float(loss) - float(g[name + ".loss"])) <= 1e-6 * max(1.0, abs(float(g[name + ".loss"])))
+    assert len(set(t.tolist())) > 2                          # the rows really have different timesteps
+
+
+def test_projection_loss_oracle():
+    g = golden("training")
+    A, B = op.double_integrator(0.1)
+    P = op.projection_matrix(A, B, cases.H)
+    norm = cases.NormalizerStub(4, 2)
+    stats = [torch.from_numpy(v) for v in (norm.obs_mean, norm.obs_std, norm.action_mean, norm.action_std)]
+    x = torch.from_numpy(cases.projection_input("train_projloss"))
+    v = float(op.projection_violation(x, P, 4, *stats))
+    assert abs(v - float(g["projection_loss.compute"])) <= 1e-5 * float(g["projection_loss.compute"])
+    assert abs(0.1 * v - float(g["projection_loss.weighted"])) <= 1e-5 * float(g["projection_loss.weighted"])
+
+
 def test_truncated_schedule_out_of_range_raises():
     """sampling with more steps than the trained schedule fails in gather."""
     sched = od.schedule_buffers("cosine", 20)
