@@ -212,6 +212,7 @@ class GaussianDiffusion(nn.Module):
         engine has no backward pass — so this evaluates a validation /
         monitoring loss; calling ``.backward()`` on it raises as for any graph-less tensor."""
         batch = x_start.shape[0]
+        self._engine(x_start.device)              # bind schedule / options before the model call
         t = torch.randint(0, self.n_timesteps, (batch,), device=x_start.device).long()
         noise = torch.randn_like(x_start)
         x_noisy = self.q_sample(x_start, t, noise)
