@@ -1,0 +1,381 @@
+// conv_cc.hpp — the small-batch ("consumer-combine") form of the TemporalUnet convs.
+//
+// At batch 1..8 a conv layer has a few hundred rows at most and the step is a chain of ~30
+// all-to-all seams: every launch costs a kernel boundary plus dependent memory round trips, the
+// arithmetic is noise.  The batch-256 kernel (conv_gemm.hpp) splits K over blocks and lets the last
+// arriver of a tile combine the partial tiles and run the GroupNorm / Mish epilogue; at batch 1 that
+// in-kernel seam (release fence, ticket, acquire fence, serial slab reads) is most of each launch
+// (19 us for a 512->512 layer, rocprofv3).  This file turns the seam into the kernel boundary that
+// is there anyway:
+//
+//   * a conv launch ONLY produces partial sums: block (K slice, M tile, N tile) multiplies its
+//     slice of input channels and stores a raw partial tile — no bias, no norm, no ticket;
+//   * the CONSUMER of a tensor finishes it while staging its input: it adds the producer's partial
+//     slabs in slice order, the bias, normalises each (sample, group) with GroupNorm statistics it
+//     computes itself (two-pass, fp32), applies Mish, the time embedding and the residual, and keeps
+//     the result in LDS as its A operand.  The blocks of M tile 0 also write that finished slice to
+//     the tensor's ordinary activation buffer, which later readers (residual adds, skip
+//     connections) use as is.
+//
+// Same arithmetic as the reference chain F.conv1d -> F.group_norm -> F.mish -> adds
+// (m_diffuser/models/temporal_unet.py:57-122, :35-54), fp32 throughout, fixed summation order
+// (bit-reproducible run to run); only the order of fp32 additions differs from conv_gemm.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_gemm.hpp"
+#include "pointwise.hpp"
+
+namespace dad {
+
+// One input of a CC conv: either a finished tensor (nsl == 0) or a tensor still in pieces.
+struct CcSrc {
+    const float* data;     // nsl == 0: [rows][C] finished tensor;  nsl > 0: [nsl][rows][C] partial sums
+    int32_t nsl;           // partial slabs to add (<= CC_MAX_SLABS)
+    int32_t C;             // channels (row stride) of this tensor
+    int32_t rows;          // rows of the whole tensor (B * L): slab stride = rows * C
+    int32_t cpg;           // channels per GroupNorm group (when gamma != nullptr)
+    const float* bias;     // [C]
+    const float* gamma;    // [C] GroupNorm weight -> normalise + Mish; nullptr: plain sum + bias
+    const float* beta;     // [C]
+    const float* temb;     // [C] time-embedding row added after Mish, or nullptr
+    const float* res;      // [rows][C] finished residual tensor added last, or nullptr
+    const float* rslab;    // [nrs][rows][C] partial sums of the riding 1x1 residual conv, or nullptr
+    const float* rbias;    // [C]
+    int32_t nrs;
+    int32_t pad_;
+    float* mat;            // [rows][C] where M-tile-0 blocks store the finished values, or nullptr
+};
+
+struct CcParams {
+    CcSrc src0, src1;      // virtual channel concat [src0 | src1]; src1.C == 0: none
+    const float* w;        // packed [cin_pad/16][wtaps][M][16]
+    int32_t wtaps;         // tap slots of the weight image
+    int32_t cin0, cin1;    // channels taken from src0 / src1
+    int32_t M;             // GEMM columns (2 * C_out for the transposed conv)
+    int32_t B, Lin, Lout;  // batch rows, per-sample GEMM lengths
+    int32_t lshift, lshift_in;
+    int32_t interleave;    // transposed conv: column m < M/2 -> row 2l, else row 2l + 1
+    int32_t slice_ch;      // input channels per K slice: multiple of 32 and of the source's group width
+    float* oslab;          // [kslices][out_rows][out_cols] this conv's partial sums
+    float* orslab;         // same for the riding 1x1 conv, or nullptr
+    int32_t out_rows;      // rows of the output tensor (B * L_final)
+};
+
+constexpr int CC_MAX_SLABS = 8;
+constexpr int CC_THREADS = 512;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Finished values of rows [r0, r0 + nrows) x channels [c0, c0 + nch) of `s` into LDS:
+//   dst[(row_map(r)) * ld + (c - c0)]   with row_map(r) = (r / L) * seg + pad + (r % L)
+// (seg = L + 2 pad: zero halo rows around every sample; pass seg = L, pad = 0 for none).
+// nch is a multiple of 4 except for the ragged external trajectory (C = transition_dim), whose
+// channels beyond C read as zero.  All threads of the block take part; ends with a barrier.
+// `publish`: also store the finished values to s.mat.
+__device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
+                                               int nrows_tile, int L, int lshiftL, int seg, int pad, int c0,
+                                               int nch, bool publish, int tid, int lane, int wave) {
+    const int q4 = nch >> 2;
+    const long sstride = (long)s.rows * s.C;
+    const bool plain = s.nsl == 0;
+    const bool gn = !plain && s.gamma != nullptr;
+    // ---- pass A: partial sums (+ bias), or the finished tensor, into LDS; zero halos -------
+    for (int i = tid; i < nrows_tile * q4; i += CC_THREADS) {
+        const int r = i / q4, q = i - r * q4;
+        const int smp = r >> lshiftL, l = r & (L - 1);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = c0 + 4 * q;
+        if (r < nrows_valid && c < s.C) {
+            const long off = (long)(r0 + r) * s.C + c;
+            if (plain) {
+                if ((s.C & 3) == 0) {
+                    v = ldg4(s.data + off);
+                } else {                                    // external trajectory: C = transition_dim
+                    const float* g = s.data + off;
+                    const int left = s.C - c;
+                    v.x = g[0];
+                    if (left > 1) v.y = g[1];
+                    if (left > 2) v.z = g[2];
+                    if (left > 3) v.w = g[3];
+                }
+            } else {
+                // all CC_MAX_SLABS loads are issued unconditionally (slabs that do not exist re-read
+                // the last one and are weighted 0): branch-free, so they fly together
+                float4 part[CC_MAX_SLABS];
+#pragma unroll
+                for (int k = 0; k < CC_MAX_SLABS; ++k)
+                    part[k] = ldg4(s.data + (long)min(k, s.nsl - 1) * sstride + off);
+                v = part[0];
+#pragma unroll
+                for (int k = 1; k < CC_MAX_SLABS; ++k)
+                    if (k < s.nsl) { v.x += part[k].x; v.y += part[k].y; v.z += part[k].z; v.w += part[k].w; }
+                const float4 b = ldg4(s.bias + c);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                // no norm (down / up-sampling convs: bias only): finished here
+                if (!gn && publish && s.mat != nullptr) *reinterpret_cast<float4*>(s.mat + off) = v;
+            }
+        }
+        *reinterpret_cast<float4*>(dst + (smp * seg + pad + l) * ld + 4 * q) = v;
+    }
+    if (pad > 0) {
+        const int nsmp = nrows_tile >> lshiftL;
+        for (int i = tid; i < nsmp * 2 * pad * q4; i += CC_THREADS) {
+            const int hr = i / q4, q = i - hr * q4;
+            const int smp = hr / (2 * pad), j = hr - smp * (2 * pad);
+            const int row = smp * seg + (j < pad ? j : L + j);
+            *reinterpret_cast<float4*>(dst + row * ld + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    if (!gn) return;
+    // ---- pass B: GroupNorm(8) per (sample, group) -> Mish -> + time embedding -> + residual ----
+    // one (sample, group) pair per wave at a time; two-pass mean / biased variance in fp32
+    const int cpg = s.cpg;
+    const int groups = nch / cpg;                           // whole groups (host guarantees)
+    const int nsmp = nrows_valid >> lshiftL;
+    const int cnt = L * cpg;
+    const float inv_cnt = 1.0f / (float)cnt;
+    const int cpg_sh = 31 - __clz(cpg);
+    for (int pr = wave; pr < nsmp * groups; pr += CC_THREADS / 64) {
+        const int smp = pr / groups, g = pr - smp * groups;
+        float* base = dst + (smp * seg + pad) * ld + g * cpg;
+        float sum = 0.0f;
+        for (int e = lane; e < cnt; e += 64) sum += base[(e >> cpg_sh) * ld + (e & (cpg - 1))];
+        const float mean = wave_sum(sum) * inv_cnt;
+        float sq = 0.0f;
+        for (int e = lane; e < cnt; e += 64) {
+            const float d = base[(e >> cpg_sh) * ld + (e & (cpg - 1))] - mean;
+            sq += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_cnt + 1e-5f);
+        for (int e = lane; e < cnt; e += 64) {
+            const int l = e >> cpg_sh, cl = e & (cpg - 1);
+            const int c = c0 + g * cpg + cl;
+            float y = mish_fast_f32((base[l * ld + cl] - mean) * rstd * s.gamma[c] + s.beta[c]);
+            const long off = (long)(r0 + smp * L + l) * s.C + c;
+            float extra = s.temb != nullptr ? s.temb[c] : 0.0f;
+            if (s.res != nullptr) extra += s.res[off];
+            if (s.rslab != nullptr) {
+                const long rs = (long)s.rows * s.C;
+                float rsum = s.rslab[off];
+                for (int k = 1; k < s.nrs; ++k) rsum += s.rslab[k * rs + off];
+                extra += rsum + s.rbias[c];
+            }
+            y += extra;
+            base[l * ld + cl] = y;
+            if (publish && s.mat != nullptr) s.mat[off] = y;
+        }
+    }
+    __syncthreads();
+}
+
+// LDS floats of one conv_cc block: [X rows][slice + 4] + [weight taps][32][slice + 4], or the
+// exchange tile [8 waves][32][36] (+ the ride's) after the K loop.
+__host__ __device__ inline size_t cc_lds_floats(int slice_ch, int taps, int wtaps, int Lin, int Lout) {
+    const int spt = 32 / Lout;
+    const size_t xs = slice_ch + 4;
+    const size_t k = (size_t)spt * (Lin + 2 * (taps / 2)) * xs + (size_t)wtaps * 32 * xs;
+    const size_t e = (size_t)2 * 8 * 32 * 36;
+    return k > e ? k : e;
+}
+
+// grid = (K slices, M / 32, N tiles of 32 GEMM rows); 8 waves: every wave owns the 32 x 32 tile and
+// takes every 8th (tap, 8-channel group) unit of the slice (intra-block split-K over all waves).
+template <int TAPS, int STRIDE, bool RES>
+__global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
+    constexpr int PAD = TAPS / 2;
+    constexpr int WTAPS = TAPS + (RES ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* const smem4 = reinterpret_cast<float4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    const int kb = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
+    const int Lin = p.Lin, Lout = p.Lout, M = p.M;
+    const int SPT = 32 >> p.lshift;                    // whole samples per tile
+    const int SEG = Lin + 2 * PAD;
+    const int XROWS = SPT * SEG;
+    const int s0 = nt * SPT;
+    const int nvalid = min(SPT, p.B - s0);
+    const int m0 = mt * 32;
+    const int SL = p.slice_ch;
+    const int XS = SL + 4;                             // LDS row stride: odd number of 16-byte slots
+    const int XS4 = XS >> 2;
+    float* const Xb = smem;
+    float* const Wb = smem + XROWS * XS;
+
+    // ---- weights of this (K slice, M tile): global -> registers -> LDS, all in flight at once --
+    const int c0 = kb * SL;                            // first input channel of the slice
+    const int ngr = SL >> 4;                           // 16-channel granules in the slice
+    const int n_w4 = ngr * WTAPS * 32 * 4;             // float4 to stage
+    constexpr int WPT = 12;                            // >= 128 ch * 6 taps * 32 rows / 4 / 512 threads
+    float4 wreg[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int e = tid + i * CC_THREADS;
+        wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < n_w4) {
+            const int q = e & 3, mm = (e >> 2) & 31, gt = e >> 7;       // gt = gr * WTAPS + tap
+            const int gr = gt / WTAPS, tap = gt - gr * WTAPS;
+            wreg[i] = ldg4(p.w + ((long)(((c0 >> 4) + gr) * p.wtaps + tap) * M + m0 + mm) * 16 + q * 4);
+        }
+    }
+
+    // ---- input slice: finish the producer's tensor into LDS (see file header) ----------------
+    const bool second = p.cin1 > 0 && c0 >= p.cin0;
+    const CcSrc& src = second ? p.src1 : p.src0;
+    const int cs0 = second ? c0 - p.cin0 : c0;         // first channel inside that source
+    const int cin_src = second ? p.cin1 : p.cin0;
+    const int nch = min(SL, ((cin_src - cs0) + 3) & ~3);   // channels to stage (rest of the slice: zero)
+    if (nch < SL) {                                    // zero the columns the staging leaves untouched
+        for (int i = tid; i < XROWS * XS4; i += CC_THREADS) smem4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    cc_build_input(src, Xb, XS, s0 * Lin, nvalid * Lin, SPT * Lin, Lin, p.lshift_in, SEG, PAD, cs0, nch,
+                   mt == 0, tid, lane, wave);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int e = tid + i * CC_THREADS;
+        if (e < n_w4) {
+            const int q = e & 3, mm = (e >> 2) & 31, gt = e >> 7;
+            const int gr = gt / WTAPS, tap = gt - gr * WTAPS;
+            *reinterpret_cast<float4*>(Wb + (tap * 32 + mm) * XS + gr * 16 + q * 4) = wreg[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- K loop: no barriers, every operand is resident ---------------------------------------
+    f32x16 acc, acc2, acc3, acc4, accr, accr2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; acc4[r] = 0.f; accr[r] = 0.f; accr2[r] = 0.f; }
+    const int phase_shift = (TAPS == 2 && p.interleave && m0 >= (M >> 1)) ? 1 : 0;
+    const int arow4 = (((l32 >> p.lshift) * SEG + (l32 & (Lout - 1)) * STRIDE + phase_shift) * XS + 4 * h) >> 2;
+    const int brow4 = (XROWS * XS + l32 * XS + 4 * h) >> 2;
+    const int G = SL >> 3;                             // 8-channel groups in the slice
+    const int U = WTAPS * G;
+    for (int u = wave; u < U; u += CC_THREADS / 64) {
+        const int wtap = u / G, g = u - wtap * G;
+        const int tap = (RES && wtap == TAPS) ? PAD : wtap;
+        const float4 a = smem4[arow4 + tap * XS4 + g * 2];
+        const float4 b = smem4[brow4 + wtap * 32 * XS4 + g * 2];
+        if (RES && wtap == TAPS) {
+            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, accr, 0, 0, 0);
+            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, accr2, 0, 0, 0);
+            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, accr, 0, 0, 0);
+            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, accr2, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc3, 0, 0, 0);
+            acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc4, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                   // all fragment reads done: LDS becomes the exchange tile
+
+    // ---- the 8 waves' partial tiles meet in LDS; one float4 of the block's tile per thread ------
+    constexpr int ES = 36;
+    float* const E = smem;                             // [8][32][ES]
+    float* const ER = smem + 8 * 32 * ES;              // the ride's
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        E[(wave * 32 + row) * ES + l32] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
+        if (RES) ER[(wave * 32 + row) * ES + l32] = accr[r] + accr2[r];
+    }
+    __syncthreads();
+    const int which = tid >> 8;                        // 0: the conv, 1: the riding 1x1 conv
+    if (which == 1 && !RES) return;
+    const int t8 = tid & 255;
+    const int row = t8 >> 3, col = (t8 & 7) * 4;
+    const float* q = (which ? ER : E) + row * ES + col;
+    float4 v = *reinterpret_cast<const float4*>(q);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+        const float4 u = *reinterpret_cast<const float4*>(q + w * 32 * ES);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int smp = row >> p.lshift, l = row & (Lout - 1);
+    if (smp >= nvalid) return;
+    const int em = m0 + col;
+    long off;
+    int ocols;
+    if (!p.interleave) {
+        ocols = M;
+        off = (long)((s0 + smp) * Lout + l) * M + em;
+    } else {
+        const int half = M >> 1, ph = em >= half;
+        ocols = half;
+        off = (long)((s0 + smp) * (2 * Lout) + 2 * l + ph) * half + (em - ph * half);
+    }
+    float* out = (which ? p.orslab : p.oslab) + (long)kb * p.out_rows * ocols + off;
+    *reinterpret_cast<float4*>(out) = v;
+}
+
+// ------------------------------------------------------------------ final conv + posterior, CC form
+// One block per sample: finishes final_conv[0]'s output (GroupNorm over whole samples) into LDS,
+// then the 1x1 output conv and the posterior update exactly as final_posterior_kernel does.
+struct FinalCcParams {
+    CcSrc src;               // final_conv[0]'s output, still in pieces
+    FinalParams f;           // everything else (f.act unused)
+};
+
+__host__ __device__ inline size_t final_cc_lds_floats(int td, int dim, int H) {
+    return (size_t)td * dim + ((td + 3) & ~3) + (size_t)H * (dim + 4);
+}
+
+__global__ __launch_bounds__(CC_THREADS) void final_cc_kernel(const FinalCcParams pp) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];
+    const FinalParams& p = pp.f;
+    const int td = p.td, dim = p.dim, H = p.H;
+    const int rs = dim + 4;
+    float* wl = ws;                        // [td][dim]
+    float* bl = wl + td * dim;             // [td] (+ pad to 4)
+    float* tile = bl + ((td + 3) & ~3);    // [H][dim + 4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int dq = dim >> 2;
+    for (int i = tid; i < td * dq; i += CC_THREADS)
+        *reinterpret_cast<float4*>(wl + i * 4) = ldg4(p.w + i * 4);
+    for (int i = tid; i < td; i += CC_THREADS) bl[i] = p.bias[i];
+    cc_build_input(pp.src, tile, rs, b * H, H, H, H, 31 - __clz(H), H, 0, 0, dim, false, tid, lane, wave);
+    __syncthreads();
+    for (int o = tid; o < H * td; o += CC_THREADS) {
+        const int l = o / td, j = o - l * td;
+        const float* wr = wl + j * dim;
+        const float* arow = tile + l * rs;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;       // four chains, summed pairwise
+        for (int c = 0; c < dim; c += 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + c);
+            const float4 av = *reinterpret_cast<const float4*>(arow + c);
+            a0 = fmaf(wv.x, av.x, a0); a1 = fmaf(wv.y, av.y, a1);
+            a2 = fmaf(wv.z, av.z, a2); a3 = fmaf(wv.w, av.w, a3);
+        }
+        const float out = ((a0 + a1) + (a2 + a3)) + bl[j];
+        const long idx = ((long)b * H + l) * td + j;
+        if (p.eps_out != nullptr) p.eps_out[idx] = out;
+        if (p.x_out_disabled && p.mean_out == nullptr) continue;
+        const float xv = p.x[idx];
+        float x0 = p.predict_epsilon ? p.c_recip * xv - p.c_recipm1 * out : out;
+        if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float mean = p.coef1 * x0 + p.coef2 * xv;
+        if (p.guide != nullptr) mean = mean + p.guide_scale * p.guide[idx];
+        if (p.mean_out != nullptr) p.mean_out[idx] = mean;
+        if (p.x_out_disabled) continue;
+        const float z = (p.noise != nullptr)
+                            ? p.noise[idx]
+                            : philox_normal(p.elem_offset + (uint64_t)idx, p.draw,
+                                            p.seed_dev != nullptr ? (uint64_t)*p.seed_dev : p.seed);
+        float xn = mean + p.sigma * z;
+        if (l == 0 && p.cond0 != nullptr) xn = p.cond0[(p.cond_per_row ? (long)b * td : 0) + j];
+        p.x[idx] = xn;
+    }
+}
+
+}  // namespace dad

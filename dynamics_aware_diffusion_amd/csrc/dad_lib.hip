@@ -22,6 +22,7 @@
 #include "host_plan.hpp"
 #include "conv_gemm.hpp"
 #include "pointwise.hpp"
+#include "conv_cc.hpp"
 
 using namespace dadhost;
 
@@ -184,6 +185,11 @@ int configure_kernels() {
                                     (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    const void* cc_kernels[] = {(const void*)dad::conv_cc<5, 1, false>, (const void*)dad::conv_cc<5, 1, true>,
+                                (const void*)dad::conv_cc<3, 2, false>, (const void*)dad::conv_cc<2, 1, false>,
+                                (const void*)dad::final_cc_kernel};
+    for (const void* k : cc_kernels)
+        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
@@ -265,8 +271,68 @@ int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
     return DAD_OK;
 }
 
+// ------------------------------------------------------------------ small-batch (CC) launches
+// The tensor `in` names, as the consumer must read it (conv_cc.hpp).
+dad::CcSrc cc_source(dad_model* m, const CcPlan& cc, const CcInput& in, int channels, const float* xext,
+                     float* ws, int batch, int t) {
+    dad::CcSrc s{};
+    auto buf = [&](int id) -> float* { return ws + m->plan.bufs[id].offset * (long)batch; };
+    float* slabs = ws + m->plan.floats_per_sample * (long)batch;
+    s.C = channels;
+    if (in.kind == 1) { s.data = xext; s.rows = batch * m->cfg.horizon; return s; }
+    if (in.kind == 2) { s.data = buf(in.buf); return s; }
+    const ConvOp& q = m->plan.convs[in.producer];
+    const CcOp& qo = cc.ops[in.producer];
+    s.data = slabs + qo.oslab;
+    s.nsl = qo.kslices;
+    s.C = qo.out_cols;
+    s.rows = qo.out_rows;
+    s.bias = q.d_bias;
+    if (!q.norm.empty()) { s.gamma = q.d_gamma; s.beta = q.d_beta; s.cpg = q.cout / 8; }
+    if (q.temb_off >= 0) s.temb = m->d_temb_table + (long)t * m->plan.temb_width + q.temb_off;
+    if (qo.res_kind == 1) s.res = xext;
+    else if (qo.res_kind == 2) s.res = buf(qo.res_buf);
+    else if (qo.res_kind == 3) {
+        const CcOp& r = cc.ops[qo.res_ride];
+        s.rslab = slabs + r.orslab; s.nrs = r.kslices; s.rbias = m->plan.convs[qo.res_ride].d_rbias;
+    }
+    s.mat = buf(in.buf);
+    return s;
+}
+
+int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float* ws, int batch, int t,
+                hipStream_t st) {
+    const ConvOp& op = m->plan.convs[i];
+    const CcOp& o = cc.ops[i];
+    dad::CcParams p{};
+    p.src0 = cc_source(m, cc, o.in0, op.cin0, xext, ws, batch, t);
+    if (o.in1.kind != 0) p.src1 = cc_source(m, cc, o.in1, op.cin1, xext, ws, batch, t);
+    p.w = op.d_w; p.wtaps = op.wtaps();
+    p.cin0 = op.cin0; p.cin1 = op.cin1; p.M = op.M;
+    p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout;
+    p.lshift = ilog2(op.Lout); p.lshift_in = ilog2(op.Lin);
+    p.interleave = op.kind == CONV_UP;
+    p.slice_ch = o.slice_ch;
+    float* slabs = ws + m->plan.floats_per_sample * (long)batch;
+    p.oslab = slabs + o.oslab;
+    p.orslab = o.orslab >= 0 ? slabs + o.orslab : nullptr;
+    p.out_rows = o.out_rows;
+    const void* kern = nullptr;
+    if (op.taps == 5 && op.stride == 1) kern = op.ride ? (const void*)dad::conv_cc<5, 1, true> : (const void*)dad::conv_cc<5, 1, false>;
+    else if (op.taps == 3 && op.stride == 2) kern = (const void*)dad::conv_cc<3, 2, false>;
+    else if (op.taps == 2 && op.stride == 1) kern = (const void*)dad::conv_cc<2, 1, false>;
+    if (!kern) return fail(DAD_E_INVALID, "no small-batch kernel for %s (taps=%d stride=%d)", op.name.c_str(), op.taps, op.stride);
+    static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;
+    if (trace)
+        fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d cc slice=%d kslices=%d ntiles=%d%s\n", op.name.c_str(), batch,
+                op.M, op.taps, op.cin0 + op.cin1, op.Lout, o.slice_ch, o.kslices, o.ntiles, op.ride ? " +res1x1" : "");
+    void* args[] = {&p};
+    HIP_TRY(hipLaunchKernel(kern, dim3(o.kslices, op.M / 32, o.ntiles), dim3(dad::CC_THREADS), args, o.lds_bytes, st));
+    return DAD_OK;
+}
+
 int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStream_t st,
-             const int32_t* trow = nullptr) {
+             const int32_t* trow = nullptr, const CcPlan* cc = nullptr) {
     // Profiling brackets the whole run of conv-GEMM launches of one denoiser evaluation with
     // ONE pair of HIP events on the launch stream (events between individual launches would
     // break the back-to-back dispatch they are meant to time).
@@ -284,6 +350,17 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
         HIP_TRY(hipEventRecord(e0, st));
     }
     const std::vector<ConvOp>& convs = m->plan.convs;
+    if (cc != nullptr) {                                  // small batch: consumer-combine kernels
+        for (size_t i = 0; i < convs.size(); ++i) {
+            if (m->profile) m->prof_flops += convs[i].flops_per_sample * batch;
+            if (!cc->ops[i].launched) continue;
+            const int rc = run_conv_cc(m, *cc, (int)i, x, ws, batch, t, st);
+            if (rc != DAD_OK) return rc;
+            if (m->profile) ++m->prof_launches;
+        }
+        if (m->profile) HIP_TRY(hipEventRecord(e1, st));
+        return DAD_OK;
+    }
     for (const ConvOp& op : convs) {
         // a residual 1x1 conv whose block's first conv carries it at this batch is not launched
         const bool rides = op.rider_of >= 0 && fused_at(*m, convs[op.rider_of], batch);
@@ -299,7 +376,7 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
 
 int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const dad_step_args* a,
               int x_out_disabled, float* eps_only, float* ws, hipStream_t st,
-              bool seed_from_device = false) {
+              bool seed_from_device = false, const CcPlan* cc = nullptr) {
     const dad_cfg& c = m->cfg;
     dad::FinalParams p{};
     p.act = ws + m->plan.bufs[m->plan.final_act].offset * (long)batch;
@@ -325,6 +402,19 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         p.elem_offset = a->row_offset * (uint64_t)c.horizon * (uint64_t)c.transition_dim;
         p.draw = a->draw;
         p.seed_dev = seed_from_device ? (const unsigned long long*)m->d_rng : nullptr;
+    }
+    if (cc != nullptr) {
+        dad::FinalCcParams fp{};
+        CcInput in; in.kind = 3; in.producer = cc->final_producer; in.buf = m->plan.final_act;
+        fp.src = cc_source(m, *cc, in, c.dim, x_ro ? x_ro : x, ws, batch, t);
+        fp.src.mat = nullptr;
+        fp.f = p;
+        const size_t lds_cc = dad::final_cc_lds_floats(c.transition_dim, c.dim, c.horizon) * sizeof(float);
+        if (lds_cc > dad::kLdsBytes)
+            return fail(DAD_E_INVALID, "final 1x1 conv does not fit LDS (td=%d, dim=%d)", c.transition_dim, c.dim);
+        hipLaunchKernelGGL(dad::final_cc_kernel, dim3(batch), dim3(dad::CC_THREADS), lds_cc, st, fp);
+        HIP_TRY(hipGetLastError());
+        return DAD_OK;
     }
     const size_t lds = dad::final_lds_floats(c.transition_dim, c.dim) * sizeof(float);
     if (lds > dad::kLdsBytes)
@@ -386,6 +476,8 @@ int dad_model_create(const dad_cfg* cfg, dad_model** out) {
     m->xcd_order = getenv("DAD_NO_XCD_ORDER") == nullptr;
     m->fuse_residual = getenv("DAD_NO_FUSE_RES") == nullptr;
     if (const char* v = getenv("DAD_SPLIT_TARGET")) m->split_target = std::max(1, atoi(v));
+    m->cc_enabled = getenv("DAD_NO_CC") == nullptr;
+    if (const char* v = getenv("DAD_CC_MAX_ROWS")) m->cc_max_rows = std::max(0, atoi(v));
     if ((rc = build_plan(m.get())) != DAD_OK) return rc;
     *out = m.release();
     return DAD_OK;
@@ -444,6 +536,7 @@ int dad_model_set_precision(dad_model* m, int32_t precision) {
         return fail(DAD_E_INVALID, "unknown precision %d (DAD_PREC_FP32 = 0, DAD_PREC_F16X3 = 1)", precision);
     if (precision != m->precision) m->finalized = false;       // weights must be re-packed
     m->precision = precision;
+    decide_kernel_families(m);
     return DAD_OK;
 }
 
@@ -547,8 +640,10 @@ int dad_unet_forward(dad_model* m, const float* x, int32_t t, float* out, int32_
     if (rc != DAD_OK) return rc;
     if (!x || !out || !workspace) return fail(DAD_E_INVALID, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = run_unet(m, x, t, batch, (float*)workspace, st)) != DAD_OK) return rc;
-    return run_final(m, nullptr, x, t, batch, nullptr, 1, out, (float*)workspace, st);
+    const CcPlan cc = cc_plan(*m, batch);
+    const CcPlan* ccp = cc.ok ? &cc : nullptr;
+    if ((rc = run_unet(m, x, t, batch, (float*)workspace, st, nullptr, ccp)) != DAD_OK) return rc;
+    return run_final(m, nullptr, x, t, batch, nullptr, 1, out, (float*)workspace, st, false, ccp);
 }
 
 int dad_unet_forward_rows(dad_model* m, const float* x, const int32_t* t_rows, float* out, int32_t batch,
@@ -568,8 +663,10 @@ int dad_denoise_step(dad_model* m, float* x, int32_t t, int32_t batch, const dad
     if (rc != DAD_OK) return rc;
     if (!x || !args || !workspace) return fail(DAD_E_INVALID, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = run_unet(m, x, t, batch, (float*)workspace, st)) != DAD_OK) return rc;
-    return run_final(m, x, nullptr, t, batch, args, x_out_disabled, nullptr, (float*)workspace, st);
+    const CcPlan cc = cc_plan(*m, batch);
+    const CcPlan* ccp = cc.ok ? &cc : nullptr;
+    if ((rc = run_unet(m, x, t, batch, (float*)workspace, st, nullptr, ccp)) != DAD_OK) return rc;
+    return run_final(m, x, nullptr, t, batch, args, x_out_disabled, nullptr, (float*)workspace, st, false, ccp);
 }
 
 int dad_project(const dad_project_args* p, float alpha, float* x, int32_t batch, int32_t horizon,
@@ -598,6 +695,8 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     const long step_elems = (long)batch * m->cfg.horizon * m->cfg.transition_dim;
 
     const bool seed_dev = use_graph && !m->profile && noise_stack == nullptr;
+    const CcPlan cc = cc_plan(*m, batch);
+    const CcPlan* ccp = cc.ok ? &cc : nullptr;
     auto enqueue_all = [&](hipStream_t st) -> int {
         for (int j = 0; j < n_steps; ++j) {
             const int t = n_steps - 1 - j;
@@ -605,10 +704,10 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
             a.noise = noise_stack ? noise_stack + (long)j * step_elems : nullptr;
             a.seed = seed; a.row_offset = row_offset; a.draw = (uint64_t)(j + 1);
             a.cond0 = cond0; a.cond_per_row = cond_per_row;
-            int r = run_unet(m, x, t, batch, (float*)workspace, st);
+            int r = run_unet(m, x, t, batch, (float*)workspace, st, nullptr, ccp);
             if (r != DAD_OK) return r;
             if ((r = run_final(m, x, nullptr, t, batch, &a, 0, nullptr, (float*)workspace, st,
-                               seed_dev)) != DAD_OK)
+                               seed_dev, ccp)) != DAD_OK)
                 return r;
             if (proj && (r = run_project(proj, proj_alphas_host[t], x, batch, m->cfg.horizon, st)) != DAD_OK)
                 return r;
@@ -637,7 +736,7 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     key.n_steps = n_steps; key.batch = batch; key.cond_per_row = cond_per_row;
     key.force_tile = m->force_tile;
     key.flags = (m->split_enabled ? 1 : 0) | (m->fuse_residual ? 2 : 0) | (m->xswz_enabled ? 4 : 0) |
-                (m->xcd_order ? 8 : 0) | (m->split_target << 8);
+                (m->xcd_order ? 8 : 0) | (ccp ? 16 : 0) | (m->split_target << 8);
     key.row_offset = row_offset;
     if (proj) {
         uint64_t hsh = 1469598103934665603ull;            // FNV-1a over the per-step alphas
@@ -705,6 +804,8 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value) {
     else if (key == "xswz") m->xswz_enabled = value != 0;
     else if (key == "xcd_order") m->xcd_order = value != 0;
     else if (key == "split_target") m->split_target = std::max(1, (int)value);
+    else if (key == "cc") m->cc_enabled = value != 0;
+    else if (key == "cc_max_rows") m->cc_max_rows = std::max(0, (int)value);
     else return fail(DAD_E_INVALID, "unknown option '%s'", name);
     return DAD_OK;
 }

@@ -132,6 +132,8 @@ struct HostModel {
     bool xswz_enabled = true;
     bool xcd_order = true;
     int split_target = 256;
+    bool cc_enabled = true;                                    // small batches take the consumer-combine kernels
+    int cc_max_rows = 256;                                     //   up to this many batch * horizon rows
     std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo
 };
 
@@ -184,6 +186,27 @@ struct Allocator {
 
 inline void expect(HostModel* m, const std::string& key, std::vector<int64_t> shape) {
     m->expected[key] = std::move(shape);
+}
+
+// Which kernel family a conv belongs to — a function of the architecture and the precision only
+// (so workspace sizes do not depend on whether weights have been loaded yet):
+//   bdir  wide-group layers (op.kc == 8) use the direct-B kernel in either arithmetic: 16-channel
+//         granules, whole 32-channel chunks, 5-tap stride-1 only (else the LDS-staged wide kernel)
+//   ride  the weight image carries the block's 1x1 residual conv as a sixth tap (fp32, LDS-staged)
+//   x3    split-f16 operands where the kernels exist for every tile this layer may get: 16-channel
+//         granules, and for the strided / transposed convs (no general staging path) whole
+//         64-channel chunks
+inline void decide_kernel_families(HostModel* m) {
+    for (ConvOp& op : m->plan.convs) {
+        const int cin_all = op.cin0 + op.cin1;
+        op.bdir = op.kc == 8 && op.kind == CONV_K5 &&
+                  (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
+        op.ride = !op.rname.empty() && !op.bdir && m->precision == DAD_PREC_FP32;
+        op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
+                (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
+                 (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
+                  ((op.cin0 & 63) == 0 && (cin_all & 63) == 0)));
+    }
 }
 
 // Emits the launch plan of TemporalUnet.forward (temporal_unet.py:199-241) including the
@@ -337,6 +360,7 @@ inline int build_plan(HostModel* m) {
         off += (b.per_sample + 3) / 4 * 4;
     }
     P.floats_per_sample = off;
+    decide_kernel_families(m);
     return DAD_OK;
 }
 
@@ -429,13 +453,7 @@ inline int pack_op(HostModel* m, ConvOp& op, PackedOp& out) {
     const HostTensor* w = need(op.name + ".weight");
     const HostTensor* b = need(op.name + ".bias");
     if (!w || !b) return fail(DAD_E_KEY, "missing key '%s.weight/.bias'", op.name.c_str());
-    // wide-group layers (op.kc == 8) use the direct-B kernel in either arithmetic: 16-channel
-    // granules, whole 32-channel chunks, 5-tap stride-1 only (else the LDS-staged wide kernel)
-    const int cin_all = op.cin0 + op.cin1;
-    op.bdir = op.kc == 8 && op.kind == CONV_K5 &&
-              (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
-    const int pack_g = op.bdir ? 16 : op.kc;
-    op.ride = !op.rname.empty() && !op.bdir && m->precision == DAD_PREC_FP32;
+    const int pack_g = op.bdir ? 16 : op.kc;            // flags: decide_kernel_families
     if (op.kind == CONV_UP) {
         out.w = pack_convT(*w, op.cin_pad, pack_g);
     } else {
@@ -450,13 +468,6 @@ inline int pack_op(HostModel* m, ConvOp& op, PackedOp& out) {
             out.rbias = rb->data;
         }
     }
-    // split-f16 operands where the kernels exist for every tile this layer may get: 16-channel
-    // granules, and for the strided / transposed convs (no general staging path) whole
-    // 64-channel chunks
-    op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
-            (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
-             (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
-              ((op.cin0 & 63) == 0 && (cin_all & 63) == 0)));
     op.c1 = 1.0f; op.c2 = 0.0f;
     if (op.x3) {
         const int sh = split_f16_image(out.w);
@@ -584,9 +595,7 @@ inline long slab_floats_for(const HostModel& m, int batch) {
     return best;
 }
 
-inline size_t workspace_bytes(const HostModel& m, int batch) {
-    return ((size_t)m.plan.floats_per_sample * (size_t)batch + (size_t)slab_floats_for(m, batch)) * sizeof(float);
-}
+inline size_t workspace_bytes(const HostModel& m, int batch);
 
 // ---------------------------------------------------------------------- launch geometry
 // Everything a conv-GEMM launch needs besides pointers, decided on the host and checked here
@@ -681,6 +690,119 @@ inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g)
     }
     g.xswz = m.xswz_enabled ? find_xswz(m, op.Lout, op.stride, op.taps / 2, (g.kc + 4) / 4, t.BN) : 0;
     return DAD_OK;
+}
+
+// ------------------------------------------------------------------ small-batch (CC) plan
+// conv_cc.hpp: convs only produce partial sums, consumers finish them.  Decided per batch on the
+// host: which launches exist, their K slices, where their partial slabs live, and for every input
+// whether it is read finished (external trajectory / already materialised) or in pieces.
+constexpr int kCcMaxSlabs = 8;
+constexpr int kCcMaxSlice = 128;
+struct CcInput {
+    int kind = 0;            // 0 none, 1 external trajectory, 2 finished tensor in a plan buffer, 3 in pieces
+    int buf = -1;            // kind 2 / 3: the tensor's activation buffer (kind 3: where it is materialised)
+    int producer = -1;       // kind 3: conv whose partial slabs these are
+};
+struct CcOp {
+    bool launched = false;   // false: the op does not exist in this form (riding 1x1 conv)
+    int slice_ch = 0, kslices = 0, ntiles = 0;
+    long oslab = 0, orslab = -1;       // float offsets into the CC slab region
+    int out_rows = 0, out_cols = 0;
+    size_t lds_bytes = 0;
+    CcInput in0, in1;
+    // how this conv's OUTPUT is finished by whoever consumes it
+    int res_kind = 0;        // 0 none, 1 external trajectory, 2 finished tensor (buffer res_buf), 3 ride of conv res_ride
+    int res_buf = -1, res_ride = -1;
+};
+struct CcPlan {
+    bool ok = false;
+    std::vector<CcOp> ops;
+    long slab_floats = 0;
+    int final_producer = -1;
+};
+
+inline CcPlan cc_plan(const HostModel& m, int batch) {
+    CcPlan P;
+    const dad_cfg& c = m.cfg;
+    const std::vector<ConvOp>& convs = m.plan.convs;
+    if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 32 ||
+        (long)batch * c.horizon > m.cc_max_rows)
+        return P;
+    for (const ConvOp& op : convs)
+        if (op.kc != 16 || op.cat0 >= 0 || op.bdir || op.x3 || (!op.rname.empty() && !op.ride)) return P;
+    P.ops.resize(convs.size());
+    std::vector<int> owner(m.plan.bufs.size(), -1);     // buffer -> conv whose output it holds
+    std::vector<char> materialised(convs.size(), 0);
+    long off = 0;
+    for (size_t i = 0; i < convs.size(); ++i) {
+        const ConvOp& op = convs[i];
+        CcOp& o = P.ops[i];
+        if (op.rider_of >= 0) { owner[op.dst] = -2 - op.rider_of; continue; }   // lives in its carrier's launch
+        o.launched = true;
+        // inputs
+        auto input = [&](int buf, CcInput& in) -> bool {
+            if (buf == -1) { in.kind = 0; return true; }
+            if (buf == -2) { in.kind = 1; return true; }
+            const int q = owner[buf];
+            if (q < 0) return false;                     // unknown producer (should not happen)
+            in.buf = buf;
+            if (materialised[q]) { in.kind = 2; return true; }
+            in.kind = 3; in.producer = q; materialised[q] = 1;
+            return true;
+        };
+        if (!input(op.src0, o.in0) || !input(op.src1, o.in1)) return P;
+        // K slices: whole GroupNorm groups of the tensor being finished, at most kCcMaxSlabs slices
+        const int cin = op.cin0 + op.cin1;
+        int need = 32;
+        for (const CcInput* in : {&o.in0, &o.in1})
+            if (in->kind == 3 && !convs[in->producer].norm.empty())
+                need = std::max(need, convs[in->producer].cout / 8);
+        int slice = need;
+        while ((cin + slice - 1) / slice > kCcMaxSlabs) slice *= 2;
+        if (slice > kCcMaxSlice) return P;
+        if (op.cin1 > 0 && op.cin0 % slice != 0) return P;     // a slice may not straddle the concat
+        o.slice_ch = slice;
+        o.kslices = (cin + slice - 1) / slice;
+        if ((long)o.kslices * slice > op.cin_pad) return P;    // weight image too short for whole slices
+        if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return P;
+        const int spt = 32 / op.Lout;
+        o.ntiles = (batch + spt - 1) / spt;
+        o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;
+        o.out_cols = op.kind == CONV_UP ? op.M / 2 : op.M;
+        o.oslab = off;
+        off += (long)o.kslices * o.out_rows * o.out_cols;
+        if (op.ride) { o.orslab = off; off += (long)o.kslices * o.out_rows * o.out_cols; }
+        // the exchange tile needs 2 * 8 * 32 * 36 floats; operands XROWS + weight rows of slice + 4
+        {
+            const size_t xs = slice + 4;
+            const size_t k = (size_t)spt * (op.Lin + 2 * (op.taps / 2)) * xs + (size_t)op.wtaps() * 32 * xs;
+            const size_t e = (size_t)2 * 8 * 32 * 36;
+            o.lds_bytes = std::max(k, e) * sizeof(float);
+        }
+        if (o.lds_bytes > dad::kLdsBytes) return P;
+        // how the output gets finished
+        if (op.res == -2) o.res_kind = 1;
+        else if (op.res >= 0) {
+            const int q = owner[op.res];
+            if (q <= -2) { o.res_kind = 3; o.res_ride = -2 - q; }
+            else if (q >= 0 && materialised[q]) { o.res_kind = 2; o.res_buf = op.res; }
+            else return P;                               // residual not finished yet: not a plan we know
+        }
+        owner[op.dst] = (int)i;
+    }
+    P.final_producer = owner[m.plan.final_act];
+    if (P.final_producer < 0 || materialised[P.final_producer]) return P;
+    P.slab_floats = off;
+    P.ok = true;
+    return P;
+}
+
+// activations, then whichever scratch the batch uses: split-K slabs or the CC partial-sum slabs
+inline size_t workspace_bytes(const HostModel& m, int batch) {
+    const CcPlan cc = cc_plan(m, batch);
+    // (both: a small batch with per-row timesteps still runs the batch-256 kernels)
+    const size_t scratch = std::max(cc.ok ? (size_t)cc.slab_floats : 0, (size_t)slab_floats_for(m, batch));
+    return ((size_t)m.plan.floats_per_sample * (size_t)batch + scratch) * sizeof(float);
 }
 
 // Bytes the parameter arena must hold: packed weights, norms, tables, time-MLP weights, flags.

@@ -65,6 +65,7 @@ class TemporalUnet(nn.Module):
     """
 
     default_precision = "fp32"      # what new instances start with (see ``precision`` below)
+    default_small_batch_kernels = True
 
     def __init__(self, transition_dim: int, dim: int = 128,
                  dim_mults: Sequence[int] = (1, 2, 4, 8), kernel_size: int = 5,
@@ -84,6 +85,10 @@ class TemporalUnet(nn.Module):
         # "f16x3" = split-f16 operands, three f16 MFMAs per product, fp32 accumulation; both meet
         # the same fp32 parity gates.  Changing it re-packs the weights on the next call.
         self.precision = type(self).default_precision
+        # Batches of up to 8 plans (batch * horizon <= 256 rows) run the consumer-combine kernels
+        # (csrc/conv_cc.hpp: convs emit partial sums, consumers finish them) — the get_action path.
+        # False keeps every batch on the batch-256 kernels with grid-level split-K.
+        self.small_batch_kernels = type(self).default_small_batch_kernels
         # engine state (not part of state_dict)
         self._engine: Optional[HipEngine] = None
         self._engine_sig = None
@@ -107,7 +112,7 @@ class TemporalUnet(nn.Module):
         sched = None
         if self._schedule is not None:
             sched = tuple((k, v.data_ptr(), v._version) for k, v in sorted(self._schedule.items()))
-        return (horizon, str(device), opts, params, sched, self.precision)
+        return (horizon, str(device), opts, params, sched, self.precision, bool(self.small_batch_kernels))
 
     def engine(self, horizon: int, device: torch.device) -> HipEngine:
         """Return the engine for (horizon, device), (re)building it if weights, schedule or
@@ -135,6 +140,7 @@ class TemporalUnet(nn.Module):
                                        "posterior_mean_coef1", "posterior_mean_coef2",
                                        "posterior_log_variance_clipped")}
         eng.load(dict(self.named_parameters()), sched)
+        eng.debug_set_option("cc", int(bool(self.small_batch_kernels)))
         self._engine, self._engine_sig = eng, sig
         return eng
 

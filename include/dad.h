@@ -205,7 +205,9 @@ int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, doub
  * additionally disables grid-level split-K.
  * dad_debug_set_option: "fuse_residual" (the 1x1 residual conv rides in its block's first conv
  * launch; 0 = always its own launch), "xswz" (LDS slot shifts), "xcd_order" (XCD-aware tile
- * order), "split_target" (blocks a split-K layer aims for).
+ * order), "split_target" (blocks a split-K layer aims for), "cc" (small batches take the
+ * consumer-combine kernels of csrc/conv_cc.hpp; 0 = always the batch-256 kernels), "cc_max_rows"
+ * (largest batch * horizon that does).
  * Results do not depend on these choices beyond fp32 summation order. */
 int dad_debug_set_tile(dad_model* m, int32_t cfg);
 int dad_debug_set_option(dad_model* m, const char* name, int32_t value);

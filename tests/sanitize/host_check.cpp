@@ -63,7 +63,7 @@ static void check_arch(const Arch& a, int precision) {
     for (size_t i = 0; i < a.mults.size(); ++i) c.channels[i] = a.dim * a.mults[i];
     c.kernel_size = 5; c.horizon = a.horizon; c.n_timesteps = 20;
     c.predict_epsilon = c.clip_denoised = 1;
-    m.precision = precision;
+    m.precision = precision;               // (build_plan decides the kernel families from it)
     int rc = check_cfg(&c);
     if (rc != DAD_OK) { printf("  %-14s refused: %s\n", a.name, g_err); return; }
     rc = build_plan(&m);
@@ -137,14 +137,6 @@ static void check_arch(const Arch& a, int precision) {
             arena += (po.w.size() + po.bias.size() + po.rbias.size()) * sizeof(float) + 3 * 256;
         }
         CHECK(arena <= arena_bytes_needed(m), "arena estimate %zu < %zu", arena_bytes_needed(m), arena);
-    } else {
-        for (ConvOp& op : m.plan.convs) {      // kernel-family flags only
-            op.bdir = op.kc == 8 && op.kind == CONV_K5 && (op.cin0 % 32) == 0 &&
-                      ((op.cin0 + op.cin1) % 32) == 0 && op.cin_pad == op.cin0 + op.cin1;
-            op.ride = !op.rname.empty() && !op.bdir && precision == DAD_PREC_FP32;
-            op.x3 = precision == DAD_PREC_F16X3 && (op.bdir || (op.kc == 16 && (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
-                    ((op.cin0 & 63) == 0 && ((op.cin0 + op.cin1) & 63) == 0))));
-        }
     }
 
     // launches: every batch size, every forced tile, with and without split-K / fusion
@@ -217,8 +209,54 @@ static void check_arch(const Arch& a, int precision) {
                 }
             }
         }
+    // small-batch (consumer-combine) plans: slabs disjoint and inside the workspace, inputs finished
+    // before they are read finished, slices whole groups, every launch fits LDS
+    m.force_tile = -1; m.split_enabled = true; m.fuse_residual = true;
+    long cc_plans = 0;
+    for (int B : {1, 2, 3, 5, 8}) {
+        const CcPlan cc = cc_plan(m, B);
+        if (!cc.ok) continue;
+        ++cc_plans;
+        CHECK(precision == DAD_PREC_FP32 && (long)B * c.horizon <= m.cc_max_rows, "CC plan outside its domain");
+        CHECK(workspace_bytes(m, B) >= ((size_t)P.floats_per_sample * B + (size_t)cc.slab_floats) * sizeof(float), "CC workspace");
+        std::vector<std::pair<long, long>> spans;
+        std::vector<char> finished(P.convs.size(), 0);
+        for (size_t i = 0; i < P.convs.size(); ++i) {
+            const ConvOp& op = P.convs[i];
+            const CcOp& o = cc.ops[i];
+            if (!o.launched) { CHECK(op.rider_of >= 0 && P.convs[op.rider_of].ride, "%s not launched", op.name.c_str()); continue; }
+            CHECK(o.kslices >= 1 && o.kslices <= kCcMaxSlabs && o.slice_ch % 32 == 0 && o.slice_ch <= kCcMaxSlice,
+                  "%s: slices %d x %d", op.name.c_str(), o.kslices, o.slice_ch);
+            CHECK((long)o.kslices * o.slice_ch >= op.cin0 + op.cin1 && (long)o.kslices * o.slice_ch <= op.cin_pad,
+                  "%s: slices do not cover the input channels", op.name.c_str());
+            CHECK(op.cin1 == 0 || op.cin0 % o.slice_ch == 0, "%s: slice straddles the concat", op.name.c_str());
+            CHECK(o.lds_bytes <= dad::kLdsBytes, "%s: CC LDS %zu", op.name.c_str(), o.lds_bytes);
+            CHECK((size_t)(o.slice_ch / 16) * op.wtaps() * 128 <= 12 * 512, "%s: weight staging registers", op.name.c_str());
+            CHECK(o.ntiles * (32 / op.Lout) >= B, "%s: tiles do not cover the batch", op.name.c_str());
+            const long n = (long)o.kslices * o.out_rows * o.out_cols;
+            spans.push_back({o.oslab, o.oslab + n});
+            if (o.orslab >= 0) spans.push_back({o.orslab, o.orslab + n});
+            CHECK((o.orslab >= 0) == op.ride, "%s: ride slab", op.name.c_str());
+            for (const CcInput* in : {&o.in0, &o.in1}) {
+                if (in->kind == 3) {
+                    CHECK(in->producer >= 0 && in->producer < (int)i && cc.ops[in->producer].launched && !finished[in->producer],
+                          "%s: reads %d in pieces twice", op.name.c_str(), in->producer);
+                    finished[in->producer] = 1;
+                    const ConvOp& q = P.convs[in->producer];
+                    if (!q.norm.empty()) CHECK(o.slice_ch % (q.cout / 8) == 0, "%s: slice splits a GroupNorm group", op.name.c_str());
+                    const CcOp& qo = cc.ops[in->producer];
+                    if (qo.res_kind == 3) CHECK(cc.ops[qo.res_ride].orslab >= 0 && qo.res_ride < in->producer, "%s: ride source", op.name.c_str());
+                }
+            }
+        }
+        CHECK(cc.final_producer >= 0 && !finished[cc.final_producer], "final conv output already finished");
+        std::sort(spans.begin(), spans.end());
+        for (size_t k = 0; k + 1 < spans.size(); ++k) CHECK(spans[k].second <= spans[k + 1].first, "CC slabs overlap");
+        if (!spans.empty()) CHECK(spans.front().first >= 0 && spans.back().second <= cc.slab_floats, "CC slabs outside their region");
+    }
     printf("  %-14s prec=%d: %zu launches in the plan, %zu buffers, %ld floats/sample, %ld launch geometries checked\n",
            a.name, precision, P.convs.size(), P.bufs.size(), P.floats_per_sample, launches);
+    (void)cc_plans;
 }
 
 int main(int argc, char** argv) {

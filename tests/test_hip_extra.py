@@ -34,6 +34,7 @@ def test_every_tile_variant_matches_oracle(tile, dev):
         diff = build(net, cases.NETS[net][4], "cosine", dev)
         eng = diff._engine(dev)
         try:
+            eng.debug_set_option("cc", 0)               # tiles belong to the batch-256 kernels
             eng.debug_set_tile(tile)
             x = torch.from_numpy(synth.normal_like(61, f"tile{tile}.{net}", (B, 32, diff.transition_dim)))
             want = _oracle_eps(net, x, 3)
@@ -42,6 +43,7 @@ def test_every_tile_variant_matches_oracle(tile, dev):
             assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, (tile, net)
         finally:
             eng.debug_set_tile(-1)
+            eng.debug_set_option("cc", int(diff.model.small_batch_kernels))
 
 
 def test_grid_split_k_is_exact_to_rounding_and_deterministic(dev):
@@ -50,6 +52,7 @@ def test_grid_split_k_is_exact_to_rounding_and_deterministic(dev):
     from dynamics_aware_diffusion_amd.utils import synth
     diff = build("pointmaze", 100, "cosine", dev)
     eng = diff._engine(dev)
+    eng.debug_set_option("cc", 0)                       # grid split-K lives in the batch-256 kernels
     for B in (1, 3, 8):
         x = torch.from_numpy(synth.normal_like(65, f"splitk.{B}", (B, 32, 6)))
         want = _oracle_eps("pointmaze", x, 42).numpy()
@@ -65,6 +68,7 @@ def test_grid_split_k_is_exact_to_rounding_and_deterministic(dev):
         assert np.array_equal(a, b)
         assert max_abs(a, want) <= TOL_STEP and max_abs(c, want) <= TOL_STEP
         assert max_abs(a, c) <= 1e-5
+    eng.debug_set_option("cc", int(diff.model.small_batch_kernels))
 
 
 def test_wide_group_tiles_on_big_architectures(dev):
@@ -154,6 +158,7 @@ def test_philox_sampling_is_sharding_invariant_and_deterministic(dev):
     diff.sampler_rng, diff.seed = "philox", 4242
     eng = diff._engine(dev)
     try:
+        eng.debug_set_option("cc_max_rows", 0 if not diff.model.small_batch_kernels else 32 * 8)
         eng.debug_set_tile(101)                        # tile 1, no grid split-K => same summation order
         pol = GuidedPolicy(diff, None)
         cond = {0: torch.from_numpy(cases.loop_condition("inv", "tiny")).to(dev)}
