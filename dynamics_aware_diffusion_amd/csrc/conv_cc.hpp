@@ -72,6 +72,102 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The GroupNorm'd form of the same thing: one (sample, group) pair per wave at a time, entirely in
+// registers.  A pair has cnt = L * cpg <= CC_MAX_PAIR elements = at most CC_F4 float4 per lane; every
+// global load of the pair (partial slabs, bias, gamma, beta, time embedding, residual or the riding
+// conv's partial slabs) is issued before the first use, the two-pass mean / biased variance runs on
+// wave shuffles, and the finished values go to LDS (and to s.mat).  No barrier inside; the caller
+// synchronises the block afterwards.
+constexpr int CC_F4 = 4;
+constexpr int CC_MAX_PAIR = CC_F4 * 4 * 64;
+__device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
+                                                  int L, int lshiftL, int seg, int pad, int c0, int nch,
+                                                  bool publish, int lane, int wave) {
+    const int cpg = s.cpg;
+    const int groups = nch / cpg;                           // whole groups (host guarantees)
+    const int nsmp = nrows_valid >> lshiftL;
+    const int cnt = L * cpg;
+    const int cnt4 = cnt >> 2;
+    const float inv_cnt = 1.0f / (float)cnt;
+    const int cq = cpg >> 2;                                // float4 per row of the pair
+    const long sstride = (long)s.rows * s.C;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pr = wave; pr < nsmp * groups; pr += CC_THREADS / 64) {
+        const int smp = pr / groups, g = pr - smp * groups;
+        float4 v[CC_F4], ex[CC_F4], gam[CC_F4], bet[CC_F4];
+        long off[CC_F4];
+        int lo[CC_F4];
+#pragma unroll
+        for (int k = 0; k < CC_F4; ++k) {
+            v[k] = zero4; ex[k] = zero4; gam[k] = zero4; bet[k] = zero4; off[k] = 0; lo[k] = -1;
+            if (k * 64 >= cnt4) continue;                   // wave-uniform: this pair has fewer float4
+            // keep the loads of at most two float4 per lane in flight (register budget)
+            if (k == 2) __builtin_amdgcn_sched_barrier(0);
+            const int j = lane + k * 64;                    // float4 index inside the pair
+            const bool on = j < cnt4;
+            const int jj = on ? j : 0;
+            const int l = jj / cq, cl = (jj - l * cq) * 4;
+            const int c = c0 + g * cpg + cl;
+            off[k] = (long)(r0 + smp * L + l) * s.C + c;
+            lo[k] = on ? (smp * seg + pad + l) * ld + g * cpg + cl : -1;
+            // every load below is unconditional (lanes past the pair re-read element 0; slabs that do
+            // not exist re-read the last one and are not added): they all fly together
+            float4 part[CC_MAX_SLABS];
+#pragma unroll
+            for (int q = 0; q < CC_MAX_SLABS; ++q) part[q] = ldg4(s.data + (long)min(q, s.nsl - 1) * sstride + off[k]);
+            const float4 b = ldg4(s.bias + c);
+            gam[k] = ldg4(s.gamma + c);
+            bet[k] = ldg4(s.beta + c);
+            float4 e = s.temb != nullptr ? ldg4(s.temb + c) : zero4;
+            if (s.res != nullptr) {
+                const float4 r = ldg4(s.res + off[k]);
+                e.x += r.x; e.y += r.y; e.z += r.z; e.w += r.w;
+            }
+            if (s.rslab != nullptr) {
+                float4 rp[CC_MAX_SLABS];
+#pragma unroll
+                for (int q = 0; q < CC_MAX_SLABS; ++q) rp[q] = ldg4(s.rslab + (long)min(q, s.nrs - 1) * sstride + off[k]);
+                float4 r = rp[0];
+#pragma unroll
+                for (int q = 1; q < CC_MAX_SLABS; ++q)
+                    if (q < s.nrs) { r.x += rp[q].x; r.y += rp[q].y; r.z += rp[q].z; r.w += rp[q].w; }
+                const float4 rb = ldg4(s.rbias + c);
+                e.x += r.x + rb.x; e.y += r.y + rb.y; e.z += r.z + rb.z; e.w += r.w + rb.w;
+            }
+            ex[k] = e;
+            float4 a = part[0];
+#pragma unroll
+            for (int q = 1; q < CC_MAX_SLABS; ++q)
+                if (q < s.nsl) { a.x += part[q].x; a.y += part[q].y; a.z += part[q].z; a.w += part[q].w; }
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            v[k] = on ? a : zero4;
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < CC_F4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        const float mean = wave_sum(sum) * inv_cnt;
+        float sq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < CC_F4; ++k)
+            if (lo[k] >= 0) {
+                const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_cnt + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < CC_F4; ++k) {
+            if (lo[k] < 0) continue;
+            float4 y;
+            y.x = mish_fast_f32((v[k].x - mean) * rstd * gam[k].x + bet[k].x) + ex[k].x;
+            y.y = mish_fast_f32((v[k].y - mean) * rstd * gam[k].y + bet[k].y) + ex[k].y;
+            y.z = mish_fast_f32((v[k].z - mean) * rstd * gam[k].z + bet[k].z) + ex[k].z;
+            y.w = mish_fast_f32((v[k].w - mean) * rstd * gam[k].w + bet[k].w) + ex[k].w;
+            *reinterpret_cast<float4*>(dst + lo[k]) = y;
+            if (publish && s.mat != nullptr) *reinterpret_cast<float4*>(s.mat + off[k]) = y;
+        }
+    }
+}
+
 // Finished values of rows [r0, r0 + nrows) x channels [c0, c0 + nch) of `s` into LDS:
 //   dst[(row_map(r)) * ld + (c - c0)]   with row_map(r) = (r / L) * seg + pad + (r % L)
 // (seg = L + 2 pad: zero halo rows around every sample; pass seg = L, pad = 0 for none).
@@ -85,12 +181,13 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
     const long sstride = (long)s.rows * s.C;
     const bool plain = s.nsl == 0;
     const bool gn = !plain && s.gamma != nullptr;
-    // ---- pass A: partial sums (+ bias), or the finished tensor, into LDS; zero halos -------
+    // ---- partial sums (+ bias), or the finished tensor, into LDS; zero halos and absent samples ----
     for (int i = tid; i < nrows_tile * q4; i += CC_THREADS) {
         const int r = i / q4, q = i - r * q4;
         const int smp = r >> lshiftL, l = r & (L - 1);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c = c0 + 4 * q;
+        if (gn && r < nrows_valid) continue;                // GroupNorm'd tensors: cc_build_input_gn
         if (r < nrows_valid && c < s.C) {
             const long off = (long)(r0 + r) * s.C + c;
             if (plain) {
@@ -118,7 +215,7 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
                 const float4 b = ldg4(s.bias + c);
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                 // no norm (down / up-sampling convs: bias only): finished here
-                if (!gn && publish && s.mat != nullptr) *reinterpret_cast<float4*>(s.mat + off) = v;
+                if (publish && s.mat != nullptr) *reinterpret_cast<float4*>(s.mat + off) = v;
             }
         }
         *reinterpret_cast<float4*>(dst + (smp * seg + pad + l) * ld + 4 * q) = v;
@@ -132,46 +229,7 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
             *reinterpret_cast<float4*>(dst + row * ld + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    __syncthreads();
-    if (!gn) return;
-    // ---- pass B: GroupNorm(8) per (sample, group) -> Mish -> + time embedding -> + residual ----
-    // one (sample, group) pair per wave at a time; two-pass mean / biased variance in fp32
-    const int cpg = s.cpg;
-    const int groups = nch / cpg;                           // whole groups (host guarantees)
-    const int nsmp = nrows_valid >> lshiftL;
-    const int cnt = L * cpg;
-    const float inv_cnt = 1.0f / (float)cnt;
-    const int cpg_sh = 31 - __clz(cpg);
-    for (int pr = wave; pr < nsmp * groups; pr += CC_THREADS / 64) {
-        const int smp = pr / groups, g = pr - smp * groups;
-        float* base = dst + (smp * seg + pad) * ld + g * cpg;
-        float sum = 0.0f;
-        for (int e = lane; e < cnt; e += 64) sum += base[(e >> cpg_sh) * ld + (e & (cpg - 1))];
-        const float mean = wave_sum(sum) * inv_cnt;
-        float sq = 0.0f;
-        for (int e = lane; e < cnt; e += 64) {
-            const float d = base[(e >> cpg_sh) * ld + (e & (cpg - 1))] - mean;
-            sq += d * d;
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_cnt + 1e-5f);
-        for (int e = lane; e < cnt; e += 64) {
-            const int l = e >> cpg_sh, cl = e & (cpg - 1);
-            const int c = c0 + g * cpg + cl;
-            float y = mish_fast_f32((base[l * ld + cl] - mean) * rstd * s.gamma[c] + s.beta[c]);
-            const long off = (long)(r0 + smp * L + l) * s.C + c;
-            float extra = s.temb != nullptr ? s.temb[c] : 0.0f;
-            if (s.res != nullptr) extra += s.res[off];
-            if (s.rslab != nullptr) {
-                const long rs = (long)s.rows * s.C;
-                float rsum = s.rslab[off];
-                for (int k = 1; k < s.nrs; ++k) rsum += s.rslab[k * rs + off];
-                extra += rsum + s.rbias[c];
-            }
-            y += extra;
-            base[l * ld + cl] = y;
-            if (publish && s.mat != nullptr) s.mat[off] = y;
-        }
-    }
+    if (gn) cc_build_input_gn(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
     __syncthreads();
 }
 
@@ -259,21 +317,29 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     const int brow4 = (XROWS * XS + l32 * XS + 4 * h) >> 2;
     const int G = SL >> 3;                             // 8-channel groups in the slice
     const int U = WTAPS * G;
-    for (int u = wave; u < U; u += CC_THREADS / 64) {
+    // fragments of unit u + 8 are read while unit u's MFMAs run
+    auto frag = [&](int u, float4& a, float4& b) {
         const int wtap = u / G, g = u - wtap * G;
         const int tap = (RES && wtap == TAPS) ? PAD : wtap;
-        const float4 a = smem4[arow4 + tap * XS4 + g * 2];
-        const float4 b = smem4[brow4 + wtap * 32 * XS4 + g * 2];
-        if (RES && wtap == TAPS) {
-            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, accr, 0, 0, 0);
-            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, accr2, 0, 0, 0);
-            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, accr, 0, 0, 0);
-            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, accr2, 0, 0, 0);
+        a = smem4[arow4 + tap * XS4 + g * 2];
+        b = smem4[brow4 + wtap * 32 * XS4 + g * 2];
+    };
+    float4 a, b;
+    if (wave < U) frag(wave, a, b);
+    for (int u = wave; u < U; u += CC_THREADS / 64) {
+        const float4 ca = a, cb = b;
+        const int un = u + CC_THREADS / 64;
+        if (un < U) frag(un, a, b);
+        if (RES && u / G == TAPS) {
+            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, accr, 0, 0, 0);
+            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, accr2, 0, 0, 0);
+            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, accr, 0, 0, 0);
+            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, accr2, 0, 0, 0);
         } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc3, 0, 0, 0);
-            acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc4, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc3, 0, 0, 0);
+            acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc4, 0, 0, 0);
         }
     }
     __syncthreads();                                   // all fragment reads done: LDS becomes the exchange tile

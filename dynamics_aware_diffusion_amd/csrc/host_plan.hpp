@@ -133,7 +133,8 @@ struct HostModel {
     bool xcd_order = true;
     int split_target = 256;
     bool cc_enabled = true;                                    // small batches take the consumer-combine kernels
-    int cc_max_rows = 256;                                     //   up to this many batch * horizon rows
+    int cc_max_rows = 512;                                     //   up to this many batch * horizon rows
+                                                               //   (measured crossover: batch 16 at H = 32)
     std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo
 };
 
@@ -765,6 +766,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         o.kslices = (cin + slice - 1) / slice;
         if ((long)o.kslices * slice > op.cin_pad) return P;    // weight image too short for whole slices
         if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return P;
+        // a (sample, group) pair of the output is normalised by one wave in registers: <= 1024 elements
+        if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > 1024) return P;
         const int spt = 32 / op.Lout;
         o.ntiles = (batch + spt - 1) / spt;
         o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;

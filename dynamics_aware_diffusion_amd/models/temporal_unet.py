@@ -85,7 +85,7 @@ class TemporalUnet(nn.Module):
         # "f16x3" = split-f16 operands, three f16 MFMAs per product, fp32 accumulation; both meet
         # the same fp32 parity gates.  Changing it re-packs the weights on the next call.
         self.precision = type(self).default_precision
-        # Batches of up to 8 plans (batch * horizon <= 256 rows) run the consumer-combine kernels
+        # Batches of up to 16 plans (batch * horizon <= 512 rows) run the consumer-combine kernels
         # (csrc/conv_cc.hpp: convs emit partial sums, consumers finish them) — the get_action path.
         # False keeps every batch on the batch-256 kernels with grid-level split-K.
         self.small_batch_kernels = type(self).default_small_batch_kernels

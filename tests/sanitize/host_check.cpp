@@ -213,7 +213,7 @@ static void check_arch(const Arch& a, int precision) {
     // before they are read finished, slices whole groups, every launch fits LDS
     m.force_tile = -1; m.split_enabled = true; m.fuse_residual = true;
     long cc_plans = 0;
-    for (int B : {1, 2, 3, 5, 8}) {
+    for (int B : {1, 2, 3, 5, 8, 13, 16, 33}) {
         const CcPlan cc = cc_plan(m, B);
         if (!cc.ok) continue;
         ++cc_plans;

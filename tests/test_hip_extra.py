@@ -158,7 +158,6 @@ def test_philox_sampling_is_sharding_invariant_and_deterministic(dev):
     diff.sampler_rng, diff.seed = "philox", 4242
     eng = diff._engine(dev)
     try:
-        eng.debug_set_option("cc_max_rows", 0 if not diff.model.small_batch_kernels else 32 * 8)
         eng.debug_set_tile(101)                        # tile 1, no grid split-K => same summation order
         pol = GuidedPolicy(diff, None)
         cond = {0: torch.from_numpy(cases.loop_condition("inv", "tiny")).to(dev)}
