@@ -61,15 +61,27 @@ struct CcParams {
     float* oslab;          // [kslices][out_rows][out_cols] this conv's partial sums
     float* orslab;         // same for the riding 1x1 conv, or nullptr
     int32_t out_rows;      // rows of the output tensor (B * L_final)
+#ifdef DAD_STAMPS
+    unsigned long long* stamps;   // diagnostic build only: [8] realtime stamps of block 0
+#endif
 };
+#ifdef DAD_STAMPS
+#define CC_STAMP(i) do { if (p.stamps != nullptr && threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0) p.stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CC_STAMP(i) do {} while (0)
+#endif
 
 constexpr int CC_MAX_SLABS = 8;
 constexpr int CC_THREADS = 512;
 
+// Sum over the 64 lanes, every lane gets it: DPP permutes inside each 16-lane row, v_readlane across
+// rows (no LDS crossbar hops: the shuffle form of this cost ~0.4 us per reduction at this clock).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);           // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);           // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);          // row_half_mirror
+    v += dpp_f32<0x140>(v);          // row_mirror
+    return rows_sum(v, 64, 0);
 }
 
 // The GroupNorm'd form of the same thing: one (sample, group) pair per wave at a time, entirely in
@@ -80,6 +92,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // synchronises the block afterwards.
 constexpr int CC_F4 = 4;
 constexpr int CC_MAX_PAIR = CC_F4 * 4 * 64;
+template <bool RIDE>
 __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
                                                   int L, int lshiftL, int seg, int pad, int c0, int nch,
                                                   bool publish, int lane, int wave) {
@@ -112,33 +125,48 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
             lo[k] = on ? (smp * seg + pad + l) * ld + g * cpg + cl : -1;
             // every load below is unconditional (lanes past the pair re-read element 0; slabs that do
             // not exist re-read the last one and are not added): they all fly together
-            float4 part[CC_MAX_SLABS];
+            // (absent operands re-read something valid and are masked afterwards: a load under a
+            // branch would make the compiler drain every outstanding load at the branch)
+            float4 part[CC_MAX_SLABS], rp[CC_MAX_SLABS];
 #pragma unroll
             for (int q = 0; q < CC_MAX_SLABS; ++q) part[q] = ldg4(s.data + (long)min(q, s.nsl - 1) * sstride + off[k]);
             const float4 b = ldg4(s.bias + c);
             gam[k] = ldg4(s.gamma + c);
             bet[k] = ldg4(s.beta + c);
-            float4 e = s.temb != nullptr ? ldg4(s.temb + c) : zero4;
-            if (s.res != nullptr) {
-                const float4 r = ldg4(s.res + off[k]);
-                e.x += r.x; e.y += r.y; e.z += r.z; e.w += r.w;
-            }
-            if (s.rslab != nullptr) {
-                float4 rp[CC_MAX_SLABS];
+            const bool has_t = s.temb != nullptr, has_r = s.res != nullptr;
+            const float4 tv = ldg4((has_t ? s.temb : s.bias) + c);
+            const float4 rv = ldg4((has_r ? s.res : s.data) + off[k]);
+            const int nrs = RIDE ? s.nrs : 1;
+            float4 rb = zero4;
 #pragma unroll
-                for (int q = 0; q < CC_MAX_SLABS; ++q) rp[q] = ldg4(s.rslab + (long)min(q, s.nrs - 1) * sstride + off[k]);
-                float4 r = rp[0];
+            for (int q = 0; q < CC_MAX_SLABS; ++q) rp[q] = zero4;
+            if constexpr (RIDE) {
 #pragma unroll
-                for (int q = 1; q < CC_MAX_SLABS; ++q)
-                    if (q < s.nrs) { r.x += rp[q].x; r.y += rp[q].y; r.z += rp[q].z; r.w += rp[q].w; }
-                const float4 rb = ldg4(s.rbias + c);
-                e.x += r.x + rb.x; e.y += r.y + rb.y; e.z += r.z + rb.z; e.w += r.w + rb.w;
+                for (int q = 0; q < CC_MAX_SLABS; ++q) rp[q] = ldg4(s.rslab + (long)min(q, nrs - 1) * sstride + off[k]);
+                rb = ldg4(s.rbias + c);
             }
+            // masks instead of branches, so that no load can be sunk under a condition
+            const float mt_ = has_t ? 1.0f : 0.0f, mr_ = has_r ? 1.0f : 0.0f, md_ = RIDE ? 1.0f : 0.0f;
+            float4 r = rp[0];
+#pragma unroll
+            for (int q = 1; q < CC_MAX_SLABS; ++q) {
+                const float mq = q < nrs ? 1.0f : 0.0f;
+                r.x = fmaf(rp[q].x, mq, r.x); r.y = fmaf(rp[q].y, mq, r.y);
+                r.z = fmaf(rp[q].z, mq, r.z); r.w = fmaf(rp[q].w, mq, r.w);
+            }
+            float4 e;
+            e.x = tv.x * mt_ + rv.x * mr_ + (r.x + rb.x) * md_;
+            e.y = tv.y * mt_ + rv.y * mr_ + (r.y + rb.y) * md_;
+            e.z = tv.z * mt_ + rv.z * mr_ + (r.z + rb.z) * md_;
+            e.w = tv.w * mt_ + rv.w * mr_ + (r.w + rb.w) * md_;
             ex[k] = e;
             float4 a = part[0];
 #pragma unroll
-            for (int q = 1; q < CC_MAX_SLABS; ++q)
-                if (q < s.nsl) { a.x += part[q].x; a.y += part[q].y; a.z += part[q].z; a.w += part[q].w; }
+            for (int q = 1; q < CC_MAX_SLABS; ++q) {
+                const float mq = q < s.nsl ? 1.0f : 0.0f;   // x * 1 + a is exact: same sums as a branch
+                a.x = fmaf(part[q].x, mq, a.x); a.y = fmaf(part[q].y, mq, a.y);
+                a.z = fmaf(part[q].z, mq, a.z); a.w = fmaf(part[q].w, mq, a.w);
+            }
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             v[k] = on ? a : zero4;
         }
@@ -229,7 +257,10 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
             *reinterpret_cast<float4*>(dst + row * ld + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if (gn) cc_build_input_gn(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+    if (gn) {       // (a uniform branch BEFORE any load: each side is straight-line code)
+        if (s.rslab != nullptr) cc_build_input_gn<true>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+        else cc_build_input_gn<false>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+    }
     __syncthreads();
 }
 
@@ -251,6 +282,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     constexpr int WTAPS = TAPS + (RES ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* const smem4 = reinterpret_cast<float4*>(smem);
+    CC_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, h = lane >> 5;
@@ -285,6 +317,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
         }
     }
 
+    CC_STAMP(1);
     // ---- input slice: finish the producer's tensor into LDS (see file header) ----------------
     const bool second = p.cin1 > 0 && c0 >= p.cin0;
     const CcSrc& src = second ? p.src1 : p.src0;
@@ -297,6 +330,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     }
     cc_build_input(src, Xb, XS, s0 * Lin, nvalid * Lin, SPT * Lin, Lin, p.lshift_in, SEG, PAD, cs0, nch,
                    mt == 0, tid, lane, wave);
+    CC_STAMP(2);
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const int e = tid + i * CC_THREADS;
@@ -307,6 +341,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
         }
     }
     __syncthreads();
+    CC_STAMP(3);
 
     // ---- K loop: no barriers, every operand is resident ---------------------------------------
     f32x16 acc, acc2, acc3, acc4, accr, accr2;
@@ -342,6 +377,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
             acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc4, 0, 0, 0);
         }
     }
+    CC_STAMP(4);
     __syncthreads();                                   // all fragment reads done: LDS becomes the exchange tile
 
     // ---- the 8 waves' partial tiles meet in LDS; one float4 of the block's tile per thread ------
@@ -355,6 +391,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
         if (RES) ER[(wave * 32 + row) * ES + l32] = accr[r] + accr2[r];
     }
     __syncthreads();
+    CC_STAMP(5);
     const int which = tid >> 8;                        // 0: the conv, 1: the riding 1x1 conv
     if (which == 1 && !RES) return;
     const int t8 = tid & 255;
@@ -381,6 +418,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     }
     float* out = (which ? p.orslab : p.oslab) + (long)kb * p.out_rows * ocols + off;
     *reinterpret_cast<float4*>(out) = v;
+    CC_STAMP(6);
 }
 
 // ------------------------------------------------------------------ final conv + posterior, CC form
