@@ -276,7 +276,9 @@ __host__ __device__ inline size_t cc_lds_floats(int slice_ch, int taps, int wtap
 
 // grid = (K slices, M / 32, N tiles of 32 GEMM rows); 8 waves: every wave owns the 32 x 32 tile and
 // takes every 8th (tap, 8-channel group) unit of the slice (intra-block split-K over all waves).
-template <int TAPS, int STRIDE, bool RES>
+// WPT: float4 of weights each thread stages = slice * weight taps * 32 rows / 4 / 512 threads, rounded
+// up: 6 covers slices of up to 64 channels, 12 the 128-channel slices of 1024-channel inputs.
+template <int TAPS, int STRIDE, bool RES, int WPT>
 __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     constexpr int PAD = TAPS / 2;
     constexpr int WTAPS = TAPS + (RES ? 1 : 0);
@@ -304,7 +306,6 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     const int c0 = kb * SL;                            // first input channel of the slice
     const int ngr = SL >> 4;                           // 16-channel granules in the slice
     const int n_w4 = ngr * WTAPS * 32 * 4;             // float4 to stage
-    constexpr int WPT = 12;                            // >= 128 ch * 6 taps * 32 rows / 4 / 512 threads
     float4 wreg[WPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {

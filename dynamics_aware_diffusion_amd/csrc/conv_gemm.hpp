@@ -515,16 +515,25 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #define DAD_FETCH_PARAMS()                                                                       \
     _Pragma("unroll") for (int k = 0; k < F4PL; ++k) {                                           \
         const int em = m0 + ecol[k];                                                             \
+        long toff = 0;                                                                           \
+        if (p.trow != nullptr)        /* per-row timesteps: the training-side forward only */    \
+            toff = (long)p.trow[min(s0 + (erow[k] >> p.lshift), p.B - 1)] * p.temb_stride;       \
         bias4[k] = ldg4(p.bias + em);                                                            \
-        gam4[k] = zero4; bet4[k] = zero4; temb4[k] = zero4; res4[k] = zero4;                     \
-        if (has_gn) { gam4[k] = ldg4(p.gamma + em); bet4[k] = ldg4(p.beta + em); }               \
-        if (p.temb != nullptr) {                                                                 \
-            const int sb = min(s0 + (erow[k] >> p.lshift), p.B - 1);                             \
-            const long toff = p.trow != nullptr ? (long)p.trow[sb] * p.temb_stride : 0;          \
-            temb4[k] = ldg4(p.temb + toff + em);                                                 \
-        }                                                                                        \
-        if (p.res != nullptr && !p.interleave && eoff[k] >= 0) res4[k] = ldg4(p.res + eoff[k]);  \
+        gam4[k] = ldg4(gptr + em);                                                               \
+        bet4[k] = ldg4(bptr + em);                                                               \
+        temb4[k] = ldg4(tptr + toff + em);                                                       \
+        res4[k] = ldg4(has_res ? p.res + max(eoff[k], 0) : p.bias + em);                         \
     }
+    // Every parameter load is UNCONDITIONAL: an absent operand reads the bias row instead and is
+    // masked where it is used (tmask / rmask below).  A load under `if (p.gamma)` made hipcc copy the
+    // loaded register at the end of the conditional block (a phi), with an s_waitcnt in front of the
+    // copy that drained the stage loads issued before it: one exposed memory round trip (~0.6 us)
+    // in the prologue of every GroupNorm'd launch (found with -DDAD_STAMPS_PROLOGUE + the ISA).
+    const float* const gptr = has_gn ? p.gamma : p.bias;
+    const float* const bptr = has_gn ? p.beta : p.bias;
+    const float* const tptr = p.temb != nullptr ? p.temb : p.bias;
+    const bool has_res = p.res != nullptr && !p.interleave;
+    const float tmask = p.temb != nullptr ? 1.0f : 0.0f, rmask = has_res ? 1.0f : 0.0f;
     DAD_PSTAMP(7);
 #pragma unroll
     for (int k = 0; k < NLD; ++k) item_load(k, c_begin);   // first global loads fly while LDS is zeroed
@@ -822,9 +831,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #pragma unroll
     for (int k = 0; k < F4PL; ++k) {
         if (eoff[k] < 0) continue;
+        // tmask, rmask in {0, 1}: fma(temb, 1, res * 1) is temb + res with one rounding, as before
         *reinterpret_cast<float4*>(p.dst + eoff[k]) =
-            make_float4(y[k][0] + (temb4[k].x + res4[k].x), y[k][1] + (temb4[k].y + res4[k].y),
-                        y[k][2] + (temb4[k].z + res4[k].z), y[k][3] + (temb4[k].w + res4[k].w));
+            make_float4(y[k][0] + fmaf(temb4[k].x, tmask, res4[k].x * rmask), y[k][1] + fmaf(temb4[k].y, tmask, res4[k].y * rmask),
+                        y[k][2] + fmaf(temb4[k].z, tmask, res4[k].z * rmask), y[k][3] + fmaf(temb4[k].w, tmask, res4[k].w * rmask));
     }
     DAD_STAMP(5);
 }

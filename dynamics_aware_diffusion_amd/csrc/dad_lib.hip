@@ -170,6 +170,16 @@ const KernTable& kernel_table() {
     return table;
 }
 
+// Small-batch conv kernels (conv_cc.hpp) by (taps, riding 1x1 conv, 128-channel K slices).
+const void* cc_kernel(int taps, bool ride, bool wide) {
+    if (taps == 5 && !ride) return wide ? (const void*)dad::conv_cc<5, 1, false, 12> : (const void*)dad::conv_cc<5, 1, false, 6>;
+    if (taps == 5 && ride) return wide ? (const void*)dad::conv_cc<5, 1, true, 12> : (const void*)dad::conv_cc<5, 1, true, 6>;
+    if (ride) return nullptr;
+    if (taps == 3) return wide ? (const void*)dad::conv_cc<3, 2, false, 12> : (const void*)dad::conv_cc<3, 2, false, 6>;
+    if (taps == 2) return wide ? (const void*)dad::conv_cc<2, 1, false, 12> : (const void*)dad::conv_cc<2, 1, false, 6>;
+    return nullptr;
+}
+
 // Every kernel may use up to the full 160 KiB of LDS; the dynamic-LDS limit is a per-device
 // function attribute, raised once per device (not lazily per launch, so that nothing but launches
 // happens under hipGraph capture).
@@ -185,11 +195,13 @@ int configure_kernels() {
                                     (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_posterior_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
-    const void* cc_kernels[] = {(const void*)dad::conv_cc<5, 1, false>, (const void*)dad::conv_cc<5, 1, true>,
-                                (const void*)dad::conv_cc<3, 2, false>, (const void*)dad::conv_cc<2, 1, false>,
-                                (const void*)dad::final_cc_kernel};
-    for (const void* k : cc_kernels)
-        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    for (int taps : {5, 3, 2})
+        for (int ride = 0; ride < 2; ++ride)
+            for (int wide = 0; wide < 2; ++wide)
+                if (const void* k = cc_kernel(taps, ride != 0, wide != 0))
+                    HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::final_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
@@ -317,10 +329,8 @@ int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float*
     p.oslab = slabs + o.oslab;
     p.orslab = o.orslab >= 0 ? slabs + o.orslab : nullptr;
     p.out_rows = o.out_rows;
-    const void* kern = nullptr;
-    if (op.taps == 5 && op.stride == 1) kern = op.ride ? (const void*)dad::conv_cc<5, 1, true> : (const void*)dad::conv_cc<5, 1, false>;
-    else if (op.taps == 3 && op.stride == 2) kern = (const void*)dad::conv_cc<3, 2, false>;
-    else if (op.taps == 2 && op.stride == 1) kern = (const void*)dad::conv_cc<2, 1, false>;
+    const bool shape_ok = (op.taps == 5 && op.stride == 1) || (op.taps == 3 && op.stride == 2) || (op.taps == 2 && op.stride == 1);
+    const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, o.slice_ch > 64) : nullptr;
     if (!kern) return fail(DAD_E_INVALID, "no small-batch kernel for %s (taps=%d stride=%d)", op.name.c_str(), op.taps, op.stride);
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;
     if (trace)
