@@ -32,7 +32,7 @@ namespace dad {
 // One input of a CC conv: either a finished tensor (nsl == 0) or a tensor still in pieces.
 struct CcSrc {
     const float* data;     // nsl == 0: [rows][C] finished tensor;  nsl > 0: [nsl][rows][C] partial sums
-    int32_t nsl;           // partial slabs to add (<= CC_MAX_SLABS)
+    int32_t nsl;           // partial slabs to add (<= 2 * CC_MAX_SLABS; more than CC_MAX_SLABS cost a second round trip)
     int32_t C;             // channels (row stride) of this tensor
     int32_t rows;          // rows of the whole tensor (B * L): slab stride = rows * C
     int32_t cpg;           // channels per GroupNorm group (when gamma != nullptr)
@@ -92,7 +92,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // synchronises the block afterwards.
 constexpr int CC_F4 = 4;
 constexpr int CC_MAX_PAIR = CC_F4 * 4 * 64;
-template <bool RIDE>
+// BIG: tensors with 9..16 partial slabs (1024-channel inputs) add them in a second, dependent batch
+// of loads; a kernel-level template parameter, so that the common kernels keep their register
+// budget (with both forms in one kernel the allocator spilled the staged weights).
+template <bool RIDE, bool BIG>
 __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
                                                   int L, int lshiftL, int seg, int pad, int c0, int nch,
                                                   bool publish, int lane, int wave) {
@@ -154,6 +157,18 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
                 r.x = fmaf(rp[q].x, mq, r.x); r.y = fmaf(rp[q].y, mq, r.y);
                 r.z = fmaf(rp[q].z, mq, r.z); r.w = fmaf(rp[q].w, mq, r.w);
             }
+            if constexpr (RIDE && BIG) {
+                if (nrs > CC_MAX_SLABS) {                   // 9..16 ride slabs: second batch
+#pragma unroll
+                    for (int q = 0; q < CC_MAX_SLABS; ++q) rp[q] = ldg4(s.rslab + (long)min(CC_MAX_SLABS + q, nrs - 1) * sstride + off[k]);
+#pragma unroll
+                    for (int q = 0; q < CC_MAX_SLABS; ++q) {
+                        const float mq = CC_MAX_SLABS + q < nrs ? 1.0f : 0.0f;
+                        r.x = fmaf(rp[q].x, mq, r.x); r.y = fmaf(rp[q].y, mq, r.y);
+                        r.z = fmaf(rp[q].z, mq, r.z); r.w = fmaf(rp[q].w, mq, r.w);
+                    }
+                }
+            }
             float4 e;
             e.x = tv.x * mt_ + rv.x * mr_ + (r.x + rb.x) * md_;
             e.y = tv.y * mt_ + rv.y * mr_ + (r.y + rb.y) * md_;
@@ -166,6 +181,16 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
                 const float mq = q < s.nsl ? 1.0f : 0.0f;   // x * 1 + a is exact: same sums as a branch
                 a.x = fmaf(part[q].x, mq, a.x); a.y = fmaf(part[q].y, mq, a.y);
                 a.z = fmaf(part[q].z, mq, a.z); a.w = fmaf(part[q].w, mq, a.w);
+            }
+            if (BIG && s.nsl > CC_MAX_SLABS) {              // 9..16 slabs (1024-channel inputs): a second,
+#pragma unroll                                              // dependent batch of loads, in slice order
+                for (int q = 0; q < CC_MAX_SLABS; ++q) part[q] = ldg4(s.data + (long)min(CC_MAX_SLABS + q, s.nsl - 1) * sstride + off[k]);
+#pragma unroll
+                for (int q = 0; q < CC_MAX_SLABS; ++q) {
+                    const float mq = CC_MAX_SLABS + q < s.nsl ? 1.0f : 0.0f;
+                    a.x = fmaf(part[q].x, mq, a.x); a.y = fmaf(part[q].y, mq, a.y);
+                    a.z = fmaf(part[q].z, mq, a.z); a.w = fmaf(part[q].w, mq, a.w);
+                }
             }
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             v[k] = on ? a : zero4;
@@ -202,6 +227,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
 // nch is a multiple of 4 except for the ragged external trajectory (C = transition_dim), whose
 // channels beyond C read as zero.  All threads of the block take part; ends with a barrier.
 // `publish`: also store the finished values to s.mat.
+template <bool BIG>
 __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
                                                int nrows_tile, int L, int lshiftL, int seg, int pad, int c0,
                                                int nch, bool publish, int tid, int lane, int wave) {
@@ -240,6 +266,10 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
 #pragma unroll
                 for (int k = 1; k < CC_MAX_SLABS; ++k)
                     if (k < s.nsl) { v.x += part[k].x; v.y += part[k].y; v.z += part[k].z; v.w += part[k].w; }
+                for (int k = CC_MAX_SLABS; k < s.nsl; ++k) {            // 9..16 slabs
+                    const float4 u = ldg4(s.data + (long)k * sstride + off);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
                 const float4 b = ldg4(s.bias + c);
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                 // no norm (down / up-sampling convs: bias only): finished here
@@ -257,9 +287,9 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
             *reinterpret_cast<float4*>(dst + row * ld + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    if (gn) {       // (a uniform branch BEFORE any load: each side is straight-line code)
-        if (s.rslab != nullptr) cc_build_input_gn<true>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
-        else cc_build_input_gn<false>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+    if (gn) {       // (uniform branches BEFORE any load: each side is straight-line code)
+        if (s.rslab != nullptr) cc_build_input_gn<true, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+        else cc_build_input_gn<false, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
     }
     __syncthreads();
 }
@@ -277,8 +307,8 @@ __host__ __device__ inline size_t cc_lds_floats(int slice_ch, int taps, int wtap
 // grid = (K slices, M / 32, N tiles of 32 GEMM rows); 8 waves: every wave owns the 32 x 32 tile and
 // takes every 8th (tap, 8-channel group) unit of the slice (intra-block split-K over all waves).
 // WPT: float4 of weights each thread stages = slice * weight taps * 32 rows / 4 / 512 threads, rounded
-// up: 6 covers slices of up to 64 channels, 12 the 128-channel slices of 1024-channel inputs.
-template <int TAPS, int STRIDE, bool RES, int WPT>
+// up: 6 covers the widest slice (64 channels, 6 taps).
+template <int TAPS, int STRIDE, bool RES, bool BIG, int WPT = 6>
 __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     constexpr int PAD = TAPS / 2;
     constexpr int WTAPS = TAPS + (RES ? 1 : 0);
@@ -329,8 +359,8 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
         for (int i = tid; i < XROWS * XS4; i += CC_THREADS) smem4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
-    cc_build_input(src, Xb, XS, s0 * Lin, nvalid * Lin, SPT * Lin, Lin, p.lshift_in, SEG, PAD, cs0, nch,
-                   mt == 0, tid, lane, wave);
+    cc_build_input<BIG>(src, Xb, XS, s0 * Lin, nvalid * Lin, SPT * Lin, Lin, p.lshift_in, SEG, PAD, cs0, nch,
+                        mt == 0, tid, lane, wave);
     CC_STAMP(2);
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
@@ -449,7 +479,7 @@ __global__ __launch_bounds__(CC_THREADS) void final_cc_kernel(const FinalCcParam
     for (int i = tid; i < td * dq; i += CC_THREADS)
         *reinterpret_cast<float4*>(wl + i * 4) = ldg4(p.w + i * 4);
     for (int i = tid; i < td; i += CC_THREADS) bl[i] = p.bias[i];
-    cc_build_input(pp.src, tile, rs, b * H, H, H, H, 31 - __clz(H), H, 0, 0, dim, false, tid, lane, wave);
+    cc_build_input<false>(pp.src, tile, rs, b * H, H, H, H, 31 - __clz(H), H, 0, 0, dim, false, tid, lane, wave);
     __syncthreads();
     for (int o = tid; o < H * td; o += CC_THREADS) {
         const int l = o / td, j = o - l * td;

@@ -458,6 +458,16 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         }
     };
 
+    // The first stage loads go out before anything else is computed: everything up to the first
+    // LDS store (epilogue ownership arithmetic, parameter fetches, halo zeroing) runs under their
+    // latency instead of in front of it.
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) item_load(k, c_begin);
+    if constexpr (BDIR) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) bload(u, c_begin);
+    }
+
     // ---- epilogue ownership (decided up front so its global loads can fly under the K loop) --
     // After the LDS exchange each thread owns F4PL float4 (4 channels x 1 position) of one
     // (GroupNorm group, sample) pair; lanes of a pair are contiguous.  Without GroupNorm the
@@ -535,12 +545,6 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const bool has_res = p.res != nullptr && !p.interleave;
     const float tmask = p.temb != nullptr ? 1.0f : 0.0f, rmask = has_res ? 1.0f : 0.0f;
     DAD_PSTAMP(7);
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) item_load(k, c_begin);   // first global loads fly while LDS is zeroed
-    if constexpr (BDIR) {
-#pragma unroll
-        for (int u = 0; u < UW; ++u) bload(u, c_begin);
-    }
     if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }   // younger than the stage loads: not waited with them
     DAD_PSTAMP(1);
     // Zero the halo rows of both X stages once (PAD rows on either side of every sample).  Real

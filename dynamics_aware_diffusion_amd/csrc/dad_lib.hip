@@ -170,13 +170,13 @@ const KernTable& kernel_table() {
     return table;
 }
 
-// Small-batch conv kernels (conv_cc.hpp) by (taps, riding 1x1 conv, 128-channel K slices).
-const void* cc_kernel(int taps, bool ride, bool wide) {
-    if (taps == 5 && !ride) return wide ? (const void*)dad::conv_cc<5, 1, false, 12> : (const void*)dad::conv_cc<5, 1, false, 6>;
-    if (taps == 5 && ride) return wide ? (const void*)dad::conv_cc<5, 1, true, 12> : (const void*)dad::conv_cc<5, 1, true, 6>;
+// Small-batch conv kernels (conv_cc.hpp) by (taps, riding 1x1 conv, an input with 9..16 partial slabs).
+const void* cc_kernel(int taps, bool ride, bool big) {
+    if (taps == 5 && !ride) return big ? (const void*)dad::conv_cc<5, 1, false, true> : (const void*)dad::conv_cc<5, 1, false, false>;
+    if (taps == 5 && ride) return big ? (const void*)dad::conv_cc<5, 1, true, true> : (const void*)dad::conv_cc<5, 1, true, false>;
     if (ride) return nullptr;
-    if (taps == 3) return wide ? (const void*)dad::conv_cc<3, 2, false, 12> : (const void*)dad::conv_cc<3, 2, false, 6>;
-    if (taps == 2) return wide ? (const void*)dad::conv_cc<2, 1, false, 12> : (const void*)dad::conv_cc<2, 1, false, 6>;
+    if (taps == 3) return big ? (const void*)dad::conv_cc<3, 2, false, true> : (const void*)dad::conv_cc<3, 2, false, false>;
+    if (taps == 2) return big ? (const void*)dad::conv_cc<2, 1, false, true> : (const void*)dad::conv_cc<2, 1, false, false>;
     return nullptr;
 }
 
@@ -197,8 +197,8 @@ int configure_kernels() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     for (int taps : {5, 3, 2})
         for (int ride = 0; ride < 2; ++ride)
-            for (int wide = 0; wide < 2; ++wide)
-                if (const void* k = cc_kernel(taps, ride != 0, wide != 0))
+            for (int big = 0; big < 2; ++big)
+                if (const void* k = cc_kernel(taps, ride != 0, big != 0))
                     HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dad::kLdsBytes));
@@ -330,7 +330,9 @@ int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float*
     p.orslab = o.orslab >= 0 ? slabs + o.orslab : nullptr;
     p.out_rows = o.out_rows;
     const bool shape_ok = (op.taps == 5 && op.stride == 1) || (op.taps == 3 && op.stride == 2) || (op.taps == 2 && op.stride == 1);
-    const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, o.slice_ch > 64) : nullptr;
+    const bool big = p.src0.nsl > dad::CC_MAX_SLABS || p.src0.nrs > dad::CC_MAX_SLABS ||
+                     p.src1.nsl > dad::CC_MAX_SLABS || p.src1.nrs > dad::CC_MAX_SLABS;
+    const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, big) : nullptr;
     if (!kern) return fail(DAD_E_INVALID, "no small-batch kernel for %s (taps=%d stride=%d)", op.name.c_str(), op.taps, op.stride);
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;
     if (trace)

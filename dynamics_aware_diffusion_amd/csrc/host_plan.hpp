@@ -697,8 +697,9 @@ inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g)
 // conv_cc.hpp: convs only produce partial sums, consumers finish them.  Decided per batch on the
 // host: which launches exist, their K slices, where their partial slabs live, and for every input
 // whether it is read finished (external trajectory / already materialised) or in pieces.
-constexpr int kCcMaxSlabs = 8;
-constexpr int kCcMaxSlice = 128;
+constexpr int kCcMaxSlabs = 16;          // slabs a consumer adds (8 per round trip)
+constexpr int kCcMaxSlice = 64;          // channels per K slice: weight tile + input slice stay well inside
+                                         // LDS and 6 float4 of weights per thread
 struct CcInput {
     int kind = 0;            // 0 none, 1 external trajectory, 2 finished tensor in a plan buffer, 3 in pieces
     int buf = -1;            // kind 2 / 3: the tensor's activation buffer (kind 3: where it is materialised)
@@ -759,6 +760,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             if (in->kind == 3 && !convs[in->producer].norm.empty())
                 need = std::max(need, convs[in->producer].cout / 8);
         int slice = need;
+        while ((cin + slice - 1) / slice > 8 && slice < kCcMaxSlice) slice *= 2;     // 8 slabs: one round trip
         while ((cin + slice - 1) / slice > kCcMaxSlabs) slice *= 2;
         if (slice > kCcMaxSlice) return P;
         if (op.cin1 > 0 && op.cin0 % slice != 0) return P;     // a slice may not straddle the concat

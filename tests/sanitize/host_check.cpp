@@ -231,7 +231,8 @@ static void check_arch(const Arch& a, int precision) {
                   "%s: slices do not cover the input channels", op.name.c_str());
             CHECK(op.cin1 == 0 || op.cin0 % o.slice_ch == 0, "%s: slice straddles the concat", op.name.c_str());
             CHECK(o.lds_bytes <= dad::kLdsBytes, "%s: CC LDS %zu", op.name.c_str(), o.lds_bytes);
-            CHECK((size_t)(o.slice_ch / 16) * op.wtaps() * 128 <= (size_t)(o.slice_ch > 64 ? 12 : 6) * 512, "%s: weight staging registers", op.name.c_str());
+            CHECK((size_t)(o.slice_ch / 16) * op.wtaps() * 128 <= (size_t)6 * 512, "%s: weight staging registers", op.name.c_str());
+            CHECK(o.kslices <= 8 || o.slice_ch == kCcMaxSlice, "%s: more than 8 slabs below the widest slice", op.name.c_str());
             CHECK(o.ntiles * (32 / op.Lout) >= B, "%s: tiles do not cover the batch", op.name.c_str());
             const long n = (long)o.kslices * o.out_rows * o.out_cols;
             spans.push_back({o.oslab, o.oslab + n});
