@@ -296,20 +296,26 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
 
 // LDS floats of one conv_cc block: [X rows][slice + 4] + [weight taps][32][slice + 4], or the
 // exchange tile [8 waves][32][36] (+ the ride's) after the K loop.
-__host__ __device__ inline size_t cc_lds_floats(int slice_ch, int taps, int wtaps, int Lin, int Lout) {
-    const int spt = 32 / Lout;
+__host__ __device__ inline size_t cc_lds_floats(int slice_ch, int taps, int wtaps, int Lin, int Lout, int nr) {
+    const int spt = nr / Lout;
     const size_t xs = slice_ch + 4;
     const size_t k = (size_t)spt * (Lin + 2 * (taps / 2)) * xs + (size_t)wtaps * 32 * xs;
-    const size_t e = (size_t)2 * 8 * 32 * 36;
+    const size_t e = (size_t)2 * 8 * nr * 36;
     return k > e ? k : e;
 }
 
-// grid = (K slices, M / 32, N tiles of 32 GEMM rows); 8 waves: every wave owns the 32 x 32 tile and
-// takes every 8th (tap, 8-channel group) unit of the slice (intra-block split-K over all waves).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// grid = (K slices, M / 32, N tiles of NR GEMM rows); 8 waves: every wave owns the whole NR x 32 tile
+// and takes every 8th (tap, channel group) unit of the slice (intra-block split-K over all waves).
+// NR = 32: v_mfma_f32_32x32x2_f32, units of 8 channels.  NR = 16 (layers of at most 16 positions: at
+// batch 1 a 32-row tile would be at most half full): v_mfma_f32_16x16x4_f32 on two 16-channel halves,
+// units of 16 channels — the same matrix-pipe cycles per unit for half the padded rows.
 // WPT: float4 of weights each thread stages = slice * weight taps * 32 rows / 4 / 512 threads, rounded
 // up: 6 covers the widest slice (64 channels, 6 taps).
-template <int TAPS, int STRIDE, bool RES, bool BIG, int WPT = 6>
+template <int TAPS, int STRIDE, bool RES, bool BIG, int NR, int WPT = 6>
 __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
+    static_assert(NR == 16 || NR == 32, "tile rows");
     constexpr int PAD = TAPS / 2;
     constexpr int WTAPS = TAPS + (RES ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     const int l32 = lane & 31, h = lane >> 5;
     const int kb = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
     const int Lin = p.Lin, Lout = p.Lout, M = p.M;
-    const int SPT = 32 >> p.lshift;                    // whole samples per tile
+    const int SPT = NR >> p.lshift;                    // whole samples per tile
     const int SEG = Lin + 2 * PAD;
     const int XROWS = SPT * SEG;
     const int s0 = nt * SPT;
@@ -375,51 +381,108 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     CC_STAMP(3);
 
     // ---- K loop: no barriers, every operand is resident ---------------------------------------
-    f32x16 acc, acc2, acc3, acc4, accr, accr2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; acc4[r] = 0.f; accr[r] = 0.f; accr2[r] = 0.f; }
     const int phase_shift = (TAPS == 2 && p.interleave && m0 >= (M >> 1)) ? 1 : 0;
-    const int arow4 = (((l32 >> p.lshift) * SEG + (l32 & (Lout - 1)) * STRIDE + phase_shift) * XS + 4 * h) >> 2;
-    const int brow4 = (XROWS * XS + l32 * XS + 4 * h) >> 2;
-    const int G = SL >> 3;                             // 8-channel groups in the slice
-    const int U = WTAPS * G;
-    // fragments of unit u + 8 are read while unit u's MFMAs run
-    auto frag = [&](int u, float4& a, float4& b) {
-        const int wtap = u / G, g = u - wtap * G;
-        const int tap = (RES && wtap == TAPS) ? PAD : wtap;
-        a = smem4[arow4 + tap * XS4 + g * 2];
-        b = smem4[brow4 + wtap * 32 * XS4 + g * 2];
-    };
-    float4 a, b;
-    if (wave < U) frag(wave, a, b);
-    for (int u = wave; u < U; u += CC_THREADS / 64) {
-        const float4 ca = a, cb = b;
-        const int un = u + CC_THREADS / 64;
-        if (un < U) frag(un, a, b);
-        if (RES && u / G == TAPS) {
-            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, accr, 0, 0, 0);
-            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, accr2, 0, 0, 0);
-            accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, accr, 0, 0, 0);
-            accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, accr2, 0, 0, 0);
-        } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc3, 0, 0, 0);
-            acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc4, 0, 0, 0);
-        }
-    }
-    CC_STAMP(4);
-    __syncthreads();                                   // all fragment reads done: LDS becomes the exchange tile
-
-    // ---- the 8 waves' partial tiles meet in LDS; one float4 of the block's tile per thread ------
     constexpr int ES = 36;
-    float* const E = smem;                             // [8][32][ES]
-    float* const ER = smem + 8 * 32 * ES;              // the ride's
+    float* const E = smem;                             // [8][NR][ES]
+    float* const ER = smem + 8 * NR * ES;              // the ride's
+    if constexpr (NR == 32) {
+        f32x16 acc, acc2, acc3, acc4, accr, accr2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        E[(wave * 32 + row) * ES + l32] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
-        if (RES) ER[(wave * 32 + row) * ES + l32] = accr[r] + accr2[r];
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; acc4[r] = 0.f; accr[r] = 0.f; accr2[r] = 0.f; }
+        const int arow4 = (((l32 >> p.lshift) * SEG + (l32 & (Lout - 1)) * STRIDE + phase_shift) * XS + 4 * h) >> 2;
+        const int brow4 = (XROWS * XS + l32 * XS + 4 * h) >> 2;
+        const int G = SL >> 3;                         // 8-channel groups in the slice
+        const int U = WTAPS * G;
+        // fragments of unit u + 8 are read while unit u's MFMAs run
+        auto frag = [&](int u, float4& a, float4& b) {
+            const int wtap = u / G, g = u - wtap * G;
+            const int tap = (RES && wtap == TAPS) ? PAD : wtap;
+            a = smem4[arow4 + tap * XS4 + g * 2];
+            b = smem4[brow4 + wtap * 32 * XS4 + g * 2];
+        };
+        float4 a, b;
+        if (wave < U) frag(wave, a, b);
+        for (int u = wave; u < U; u += CC_THREADS / 64) {
+            const float4 ca = a, cb = b;
+            const int un = u + CC_THREADS / 64;
+            if (un < U) frag(un, a, b);
+            if (RES && u / G == TAPS) {
+                accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, accr, 0, 0, 0);
+                accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, accr2, 0, 0, 0);
+                accr = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, accr, 0, 0, 0);
+                accr2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, accr2, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.x, cb.x, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.y, cb.y, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.z, cb.z, acc3, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca.w, cb.w, acc4, 0, 0, 0);
+            }
+        }
+        CC_STAMP(4);
+        __syncthreads();                               // all fragment reads done: LDS becomes the exchange tile
+        // ---- the 8 waves' partial tiles meet in LDS; one float4 of the block's tile per thread --
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            E[(wave * 32 + row) * ES + l32] = (acc[r] + acc2[r]) + (acc3[r] + acc4[r]);
+            if (RES) ER[(wave * 32 + row) * ES + l32] = accr[r] + accr2[r];
+        }
+    } else {
+        // 16-row tile: lane = (row or channel l16, k group g4); a unit is 16 channels of one tap: the
+        // float4 at channels 4*g4.. is component j of MFMA j's k index g4 — the same bijection of K
+        // for both operands, so any order is a valid summation order.
+        const int l16 = lane & 15, g4 = lane >> 4;
+        f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = c0a, c1a = c0a, c1b = c0a, r0 = c0a, r1 = c0a;
+        const int arow4 = (((l16 >> p.lshift) * SEG + (l16 & (Lout - 1)) * STRIDE + phase_shift) * XS + 4 * g4) >> 2;
+        const int brow4 = (XROWS * XS + l16 * XS + 4 * g4) >> 2;
+        const int G = SL >> 4;                         // 16-channel groups in the slice
+        const int U = WTAPS * G;
+        auto frag = [&](int u, float4& a, float4& b0, float4& b1) {
+            const int wtap = u / G, g = u - wtap * G;
+            const int tap = (RES && wtap == TAPS) ? PAD : wtap;
+            a = smem4[arow4 + tap * XS4 + g * 4];
+            b0 = smem4[brow4 + wtap * 32 * XS4 + g * 4];
+            b1 = smem4[brow4 + (wtap * 32 + 16) * XS4 + g * 4];
+        };
+        float4 a, b0, b1;
+        if (wave < U) frag(wave, a, b0, b1);
+        for (int u = wave; u < U; u += CC_THREADS / 64) {
+            const float4 ca = a, cb0 = b0, cb1 = b1;
+            const int un = u + CC_THREADS / 64;
+            if (un < U) frag(un, a, b0, b1);
+            if (RES && u / G == TAPS) {
+                r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, cb0.x, r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, cb1.x, r1, 0, 0, 0);
+                r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, cb0.y, r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, cb1.y, r1, 0, 0, 0);
+                r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, cb0.z, r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, cb1.z, r1, 0, 0, 0);
+                r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, cb0.w, r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, cb1.w, r1, 0, 0, 0);
+            } else {
+                c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, cb0.x, c0a, 0, 0, 0);
+                c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.x, cb1.x, c1a, 0, 0, 0);
+                c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, cb0.y, c0b, 0, 0, 0);
+                c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.y, cb1.y, c1b, 0, 0, 0);
+                c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, cb0.z, c0a, 0, 0, 0);
+                c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.z, cb1.z, c1a, 0, 0, 0);
+                c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, cb0.w, c0b, 0, 0, 0);
+                c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(ca.w, cb1.w, c1b, 0, 0, 0);
+            }
+        }
+        CC_STAMP(4);
+        __syncthreads();
+        // D[row = 4 * g4 + r][col = l16 (+ 16 for the second channel half)]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g4 + r;
+            E[(wave * 16 + row) * ES + l16] = c0a[r] + c0b[r];
+            E[(wave * 16 + row) * ES + 16 + l16] = c1a[r] + c1b[r];
+            if (RES) {
+                ER[(wave * 16 + row) * ES + l16] = r0[r];
+                ER[(wave * 16 + row) * ES + 16 + l16] = r1[r];
+            }
+        }
     }
     __syncthreads();
     CC_STAMP(5);
@@ -427,11 +490,12 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     if (which == 1 && !RES) return;
     const int t8 = tid & 255;
     const int row = t8 >> 3, col = (t8 & 7) * 4;
+    if (row >= NR) return;
     const float* q = (which ? ER : E) + row * ES + col;
     float4 v = *reinterpret_cast<const float4*>(q);
 #pragma unroll
     for (int w = 1; w < 8; ++w) {
-        const float4 u = *reinterpret_cast<const float4*>(q + w * 32 * ES);
+        const float4 u = *reinterpret_cast<const float4*>(q + w * NR * ES);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     const int smp = row >> p.lshift, l = row & (Lout - 1);

@@ -498,7 +498,6 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     int erow[F4PL], ecol[F4PL];
     int eoff[F4PL];                                    // output offsets fit 31 bits (host-checked)
     float4 bias4[F4PL], gam4[F4PL], bet4[F4PL], temb4[F4PL], res4[F4PL];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < F4PL; ++k) {
         const int j = lp + k * lpp;                    // float4 index inside the pair

@@ -170,14 +170,19 @@ const KernTable& kernel_table() {
     return table;
 }
 
-// Small-batch conv kernels (conv_cc.hpp) by (taps, riding 1x1 conv, an input with 9..16 partial slabs).
-const void* cc_kernel(int taps, bool ride, bool big) {
-    if (taps == 5 && !ride) return big ? (const void*)dad::conv_cc<5, 1, false, true> : (const void*)dad::conv_cc<5, 1, false, false>;
-    if (taps == 5 && ride) return big ? (const void*)dad::conv_cc<5, 1, true, true> : (const void*)dad::conv_cc<5, 1, true, false>;
+// Small-batch conv kernels (conv_cc.hpp) by (taps, riding 1x1 conv, an input with 9..16 partial
+// slabs, rows per tile).
+template <bool BIG, int NR>
+const void* cc_kernel_t(int taps, bool ride) {
+    if (taps == 5) return ride ? (const void*)dad::conv_cc<5, 1, true, BIG, NR> : (const void*)dad::conv_cc<5, 1, false, BIG, NR>;
     if (ride) return nullptr;
-    if (taps == 3) return big ? (const void*)dad::conv_cc<3, 2, false, true> : (const void*)dad::conv_cc<3, 2, false, false>;
-    if (taps == 2) return big ? (const void*)dad::conv_cc<2, 1, false, true> : (const void*)dad::conv_cc<2, 1, false, false>;
+    if (taps == 3) return (const void*)dad::conv_cc<3, 2, false, BIG, NR>;
+    if (taps == 2) return (const void*)dad::conv_cc<2, 1, false, BIG, NR>;
     return nullptr;
+}
+const void* cc_kernel(int taps, bool ride, bool big, int rows) {
+    if (rows == 16) return big ? cc_kernel_t<true, 16>(taps, ride) : cc_kernel_t<false, 16>(taps, ride);
+    return big ? cc_kernel_t<true, 32>(taps, ride) : cc_kernel_t<false, 32>(taps, ride);
 }
 
 // Every kernel may use up to the full 160 KiB of LDS; the dynamic-LDS limit is a per-device
@@ -198,8 +203,9 @@ int configure_kernels() {
     for (int taps : {5, 3, 2})
         for (int ride = 0; ride < 2; ++ride)
             for (int big = 0; big < 2; ++big)
-                if (const void* k = cc_kernel(taps, ride != 0, big != 0))
-                    HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+                for (int rows : {16, 32})
+                    if (const void* k = cc_kernel(taps, ride != 0, big != 0, rows))
+                        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
@@ -332,7 +338,7 @@ int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float*
     const bool shape_ok = (op.taps == 5 && op.stride == 1) || (op.taps == 3 && op.stride == 2) || (op.taps == 2 && op.stride == 1);
     const bool big = p.src0.nsl > dad::CC_MAX_SLABS || p.src0.nrs > dad::CC_MAX_SLABS ||
                      p.src1.nsl > dad::CC_MAX_SLABS || p.src1.nrs > dad::CC_MAX_SLABS;
-    const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, big) : nullptr;
+    const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, big, o.tile_rows) : nullptr;
     if (!kern) return fail(DAD_E_INVALID, "no small-batch kernel for %s (taps=%d stride=%d)", op.name.c_str(), op.taps, op.stride);
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;
     if (trace)

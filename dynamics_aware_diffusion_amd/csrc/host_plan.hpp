@@ -708,6 +708,7 @@ struct CcInput {
 struct CcOp {
     bool launched = false;   // false: the op does not exist in this form (riding 1x1 conv)
     int slice_ch = 0, kslices = 0, ntiles = 0;
+    int tile_rows = 32;      // GEMM rows per tile: 16 for layers of at most 16 positions (16x16x4 MFMAs)
     long oslab = 0, orslab = -1;       // float offsets into the CC slab region
     int out_rows = 0, out_cols = 0;
     size_t lds_bytes = 0;
@@ -770,7 +771,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return P;
         // a (sample, group) pair of the output is normalised by one wave in registers: <= 1024 elements
         if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > 1024) return P;
-        const int spt = 32 / op.Lout;
+        o.tile_rows = op.Lout <= 16 ? 16 : 32;
+        const int spt = o.tile_rows / op.Lout;
         o.ntiles = (batch + spt - 1) / spt;
         o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;
         o.out_cols = op.kind == CONV_UP ? op.M / 2 : op.M;
@@ -781,7 +783,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         {
             const size_t xs = slice + 4;
             const size_t k = (size_t)spt * (op.Lin + 2 * (op.taps / 2)) * xs + (size_t)op.wtaps() * 32 * xs;
-            const size_t e = (size_t)2 * 8 * 32 * 36;
+            const size_t e = (size_t)2 * 8 * o.tile_rows * 36;
             o.lds_bytes = std::max(k, e) * sizeof(float);
         }
         if (o.lds_bytes > dad::kLdsBytes) return P;

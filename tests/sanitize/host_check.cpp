@@ -233,7 +233,8 @@ static void check_arch(const Arch& a, int precision) {
             CHECK(o.lds_bytes <= dad::kLdsBytes, "%s: CC LDS %zu", op.name.c_str(), o.lds_bytes);
             CHECK((size_t)(o.slice_ch / 16) * op.wtaps() * 128 <= (size_t)6 * 512, "%s: weight staging registers", op.name.c_str());
             CHECK(o.kslices <= 8 || o.slice_ch == kCcMaxSlice, "%s: more than 8 slabs below the widest slice", op.name.c_str());
-            CHECK(o.ntiles * (32 / op.Lout) >= B, "%s: tiles do not cover the batch", op.name.c_str());
+            CHECK((o.tile_rows == 16 || o.tile_rows == 32) && o.tile_rows % op.Lout == 0 &&
+                  o.ntiles * (o.tile_rows / op.Lout) >= B, "%s: tiles do not cover the batch", op.name.c_str());
             const long n = (long)o.kslices * o.out_rows * o.out_cols;
             spans.push_back({o.oslab, o.oslab + n});
             if (o.orslab >= 0) spans.push_back({o.orslab, o.orslab + n});

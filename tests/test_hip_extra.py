@@ -541,3 +541,56 @@ def test_checkpoint_round_trip_on_the_device(arch, dev, tmp_path):
         plans = diff.p_sample_loop((2, 32, td))                     # and it samples
         assert torch.isfinite(plans).all()
     assert float((outs[0] - outs[1]).abs().max()) > 1e-3            # EMA weights are different weights
+
+
+def _random_architectures(seed: int, count: int):
+    """The generator of tests/fuzz_parity.py, frozen: (td, dim, mults, H, B, t) draws that the
+    library supports (first `count` accepted ones)."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    while len(out) < count:
+        dim = rng.choice([32, 64, 128])
+        nlev = rng.choice([1, 2, 3, 4])
+        mults = tuple([1] + [rng.choice([1, 2, 4, 8]) for _ in range(nlev - 1)])
+        H = rng.choice([8, 16, 32, 32, 64])
+        td = rng.randint(2, 24)
+        B = rng.choice([1, 2, 3, 5, 8, 13, 16])
+        t = rng.randint(0, 19)
+        if H >> (nlev - 1) < 4 or max(mults) * dim > 1024:
+            continue
+        out.append((td, dim, mults, H, B, t))
+    return out
+
+
+@pytest.mark.parametrize("arch", _random_architectures(2026, 14),
+                         ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}")
+def test_random_architectures_both_small_batch_families(arch, dev):
+    """Frozen draws of the fuzz generator (widths up to 1024, horizons 8..64, batches 1..31):
+    one forward and a short conditioned loop against the oracle, through the consumer-combine
+    kernels where the batch is small enough AND through the batch-256 kernels."""
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    from dynamics_aware_diffusion_amd.utils import synth
+    td, dim, mults, H, B, t = arch
+    state = synth.synth_unet_state(td, dim, mults, seed=500 + td, affine_jitter=0.3)
+    w = {k: torch.from_numpy(v) for k, v in state.items()}
+    x = torch.from_numpy(synth.normal_like(501, f"rnd.{arch}", (B, H, td)))
+    with torch.no_grad():
+        want = orc.unet_forward(w, x, torch.full((B,), t, dtype=torch.long))
+    T = 6
+    noise = torch.from_numpy(synth.normal_like(502, f"rnd.noise.{arch}", (T + 1, B, H, td)))
+    cond = torch.from_numpy(synth.uniform(502, f"rnd.cond.{arch}", (1, td), 0.9))
+    want_loop = orc.sample_loop(w, orc.schedule_buffers("cosine", 20), noise, T, {0: cond})
+    for small in (True, False):
+        unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+        unet.load_state_dict(w)
+        unet.small_batch_kernels = small
+        diff = GaussianDiffusion(unet, H, td - 1, 1, n_timesteps=20).to(dev)
+        got = diff.model(x.to(dev), t)
+        eng = diff._engine(dev)
+        xl = noise[0].to(dev).clone()
+        xl[:, 0] = cond.to(dev)
+        eng.sample_loop(xl, T, noise_stack=noise[1:].to(dev).contiguous(), cond0=cond.to(dev))
+        torch.cuda.synchronize()
+        assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, small
+        assert max_abs(xl.cpu().numpy(), want_loop.numpy()) <= TOL_LOOP, small
