@@ -771,7 +771,13 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return P;
         // a (sample, group) pair of the output is normalised by one wave in registers: <= 1024 elements
         if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > 1024) return P;
-        o.tile_rows = op.Lout <= 16 ? 16 : 32;
+        // 16-row tiles (16x16x4 MFMAs, half the padded rows) as long as the layer still fits one wave
+        // of blocks; beyond that the extra N tiles only re-stream the weights
+        o.tile_rows = 32;
+        if (op.Lout <= 16) {
+            const long blocks16 = (long)((batch + 16 / op.Lout - 1) / (16 / op.Lout)) * (op.M / 32) * o.kslices;
+            if (blocks16 <= 256) o.tile_rows = 16;
+        }
         const int spt = o.tile_rows / op.Lout;
         o.ntiles = (batch + spt - 1) / spt;
         o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;
