@@ -71,8 +71,25 @@ struct CcParams {
 #define CC_STAMP(i) do {} while (0)
 #endif
 
+#ifdef DAD_STAMPS
+__device__ unsigned long long* g_cc_gn_stamps = nullptr;     // set per launch by lane 0 of block 0
+#define CC_GN_STAMP(i) do { if (g_cc_gn_stamps != nullptr && lane == 0 && wave == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0 && pr == wave) g_cc_gn_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CC_GN_STAMP(i) do {} while (0)
+#endif
 constexpr int CC_MAX_SLABS = 8;
 constexpr int CC_THREADS = 512;
+
+// Kernel arguments are fetched from the kernarg segment by scalar loads that hipcc places in the
+// basic block of their FIRST USE, each batch followed by its own s_waitcnt: a kernel that first
+// touches an argument deep in its prologue pays a scalar-memory round trip there (the ISA of
+// conv_cc had six such batches in series before its first MFMA; -DDAD_STAMPS showed 1.8 us between
+// issuing the weight loads and the first load of the input).  Naming every argument as an SGPR
+// operand of an empty asm in the entry block makes all of them part of ONE batch at kernel entry.
+#define CC_PIN_SRC(S)                                                                             \
+    asm volatile("" ::"s"(S.data), "s"(S.nsl), "s"(S.C), "s"(S.rows), "s"(S.cpg), "s"(S.bias),      \
+                 "s"(S.gamma), "s"(S.beta), "s"(S.temb), "s"(S.res), "s"(S.rslab), "s"(S.rbias),    \
+                 "s"(S.nrs), "s"(S.mat))
 
 // Sum over the 64 lanes, every lane gets it: DPP permutes inside each 16-lane row, v_readlane across
 // rows (no LDS crossbar hops: the shuffle form of this cost ~0.4 us per reduction at this clock).
@@ -113,6 +130,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
         float4 v[CC_F4], ex[CC_F4], gam[CC_F4], bet[CC_F4];
         long off[CC_F4];
         int lo[CC_F4];
+        CC_GN_STAMP(8);
 #pragma unroll
         for (int k = 0; k < CC_F4; ++k) {
             v[k] = zero4; ex[k] = zero4; gam[k] = zero4; bet[k] = zero4; off[k] = 0; lo[k] = -1;
@@ -198,6 +216,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
         float sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < CC_F4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        CC_GN_STAMP(9);
         const float mean = wave_sum(sum) * inv_cnt;
         float sq = 0.0f;
 #pragma unroll
@@ -207,6 +226,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
                 sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
         const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_cnt + 1e-5f);
+        CC_GN_STAMP(10);
 #pragma unroll
         for (int k = 0; k < CC_F4; ++k) {
             if (lo[k] < 0) continue;
@@ -218,6 +238,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
             *reinterpret_cast<float4*>(dst + lo[k]) = y;
             if (publish && s.mat != nullptr) *reinterpret_cast<float4*>(s.mat + off[k]) = y;
         }
+        CC_GN_STAMP(11);
     }
 }
 
@@ -235,13 +256,36 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
     const long sstride = (long)s.rows * s.C;
     const bool plain = s.nsl == 0;
     const bool gn = !plain && s.gamma != nullptr;
-    // ---- partial sums (+ bias), or the finished tensor, into LDS; zero halos and absent samples ----
+    // zero halo rows (LDS only)
+    if (pad > 0) {
+        const int nsmp = nrows_tile >> lshiftL;
+        for (int i = tid; i < nsmp * 2 * pad * q4; i += CC_THREADS) {
+            const int hr = i / q4, q = i - hr * q4;
+            const int smp = hr / (2 * pad), j = hr - smp * (2 * pad);
+            const int row = smp * seg + (j < pad ? j : L + j);
+            *reinterpret_cast<float4*>(dst + row * ld + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (gn) {
+        // GroupNorm'd tensors.  This side of the (uniform) branch issues no global load before the
+        // pairs' own: a loop with loads in front of them made hipcc drain the weight loads first —
+        // two memory round trips in series instead of one (1.8 us of every such launch).
+        for (int i = tid + nrows_valid * q4; i < nrows_tile * q4; i += CC_THREADS) {     // absent samples: zero
+            const int r = i / q4, q = i - r * q4;
+            *reinterpret_cast<float4*>(dst + ((r >> lshiftL) * seg + pad + (r & (L - 1))) * ld + 4 * q) =
+                make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (s.rslab != nullptr) cc_build_input_gn<true, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+        else cc_build_input_gn<false, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+        __syncthreads();
+        return;
+    }
+    // ---- no norm: partial sums (+ bias), or the finished tensor, into LDS ------------------------
     for (int i = tid; i < nrows_tile * q4; i += CC_THREADS) {
         const int r = i / q4, q = i - r * q4;
         const int smp = r >> lshiftL, l = r & (L - 1);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c = c0 + 4 * q;
-        if (gn && r < nrows_valid) continue;                // GroupNorm'd tensors: cc_build_input_gn
         if (r < nrows_valid && c < s.C) {
             const long off = (long)(r0 + r) * s.C + c;
             if (plain) {
@@ -257,7 +301,7 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
                 }
             } else {
                 // all CC_MAX_SLABS loads are issued unconditionally (slabs that do not exist re-read
-                // the last one and are weighted 0): branch-free, so they fly together
+                // the last one and are not added): branch-free, so they fly together
                 float4 part[CC_MAX_SLABS];
 #pragma unroll
                 for (int k = 0; k < CC_MAX_SLABS; ++k)
@@ -272,24 +316,11 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
                 }
                 const float4 b = ldg4(s.bias + c);
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-                // no norm (down / up-sampling convs: bias only): finished here
+                // (down / up-sampling convs: bias only) finished here
                 if (publish && s.mat != nullptr) *reinterpret_cast<float4*>(s.mat + off) = v;
             }
         }
         *reinterpret_cast<float4*>(dst + (smp * seg + pad + l) * ld + 4 * q) = v;
-    }
-    if (pad > 0) {
-        const int nsmp = nrows_tile >> lshiftL;
-        for (int i = tid; i < nsmp * 2 * pad * q4; i += CC_THREADS) {
-            const int hr = i / q4, q = i - hr * q4;
-            const int smp = hr / (2 * pad), j = hr - smp * (2 * pad);
-            const int row = smp * seg + (j < pad ? j : L + j);
-            *reinterpret_cast<float4*>(dst + row * ld + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    if (gn) {       // (uniform branches BEFORE any load: each side is straight-line code)
-        if (s.rslab != nullptr) cc_build_input_gn<true, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
-        else cc_build_input_gn<false, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
     }
     __syncthreads();
 }
@@ -321,6 +352,11 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* const smem4 = reinterpret_cast<float4*>(smem);
     CC_STAMP(0);
+    CC_PIN_SRC(p.src0);
+    CC_PIN_SRC(p.src1);
+    asm volatile("" ::"s"(p.w), "s"(p.wtaps), "s"(p.cin0), "s"(p.cin1), "s"(p.M), "s"(p.B), "s"(p.Lin), "s"(p.Lout),
+                 "s"(p.lshift), "s"(p.lshift_in), "s"(p.interleave), "s"(p.slice_ch), "s"(p.oslab), "s"(p.orslab),
+                 "s"(p.out_rows));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, h = lane >> 5;
@@ -345,16 +381,20 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     float4 wreg[WPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-        const int e = tid + i * CC_THREADS;
-        wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < n_w4) {
-            const int q = e & 3, mm = (e >> 2) & 31, gt = e >> 7;       // gt = gr * WTAPS + tap
-            const int gr = gt / WTAPS, tap = gt - gr * WTAPS;
-            wreg[i] = ldg4(p.w + ((long)(((c0 >> 4) + gr) * p.wtaps + tap) * M + m0 + mm) * 16 + q * 4);
-        }
+        // unconditional (threads past the end re-read the last float4; only the LDS store below is
+        // predicated): a load under `if (e < n_w4)` got a register copy behind it at the end of the
+        // conditional block, with an s_waitcnt vmcnt(0) in front — a full memory round trip between
+        // the second and the third weight load of every launch
+        const int e = min(tid + i * CC_THREADS, n_w4 - 1);
+        const int q = e & 3, mm = (e >> 2) & 31, gt = e >> 7;           // gt = gr * WTAPS + tap
+        const int gr = gt / WTAPS, tap = gt - gr * WTAPS;
+        wreg[i] = ldg4(p.w + ((long)(((c0 >> 4) + gr) * p.wtaps + tap) * M + m0 + mm) * 16 + q * 4);
     }
 
     CC_STAMP(1);
+#ifdef DAD_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0) g_cc_gn_stamps = p.stamps;
+#endif
     // ---- input slice: finish the producer's tensor into LDS (see file header) ----------------
     const bool second = p.cin1 > 0 && c0 >= p.cin0;
     const CcSrc& src = second ? p.src1 : p.src0;

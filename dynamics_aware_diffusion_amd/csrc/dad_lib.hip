@@ -345,7 +345,7 @@ int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float*
         fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d cc slice=%d kslices=%d ntiles=%d%s\n", op.name.c_str(), batch,
                 op.M, op.taps, op.cin0 + op.cin1, op.Lout, o.slice_ch, o.kslices, o.ntiles, op.ride ? " +res1x1" : "");
 #ifdef DAD_STAMPS
-    p.stamps = g_stamps ? g_stamps + (size_t)i * 8 : nullptr;
+    p.stamps = g_stamps ? g_stamps + (size_t)i * 16 : nullptr;
 #endif
     void* args[] = {&p};
     HIP_TRY(hipLaunchKernel(kern, dim3(o.kslices, op.M / 32, o.ntiles), dim3(dad::CC_THREADS), args, o.lds_bytes, st));

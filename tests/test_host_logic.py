@@ -148,6 +148,28 @@ def test_host_logic_under_address_and_ub_sanitizers(tmp_path):
     assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr
 
 
+def test_device_kernels_use_no_scratch(tmp_path):
+    """Register spills are a performance cliff for the hand-written kernels (a spilled staging
+    register turned a 75 ms loop into 111 ms in round 2): compile the device side of the library to
+    gfx950 assembly and require `private_segment_fixed_size == 0` for every conv-GEMM kernel, the
+    pointwise kernels and the common small-batch kernels (the 9..16-slab variants, two launches of a
+    PointMaze step, are allowed their 20 bytes)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    asm = tmp_path / "dad.s"
+    src = os.path.join(ROOT, "dynamics_aware_diffusion_amd", "csrc", "dad_lib.hip")
+    run = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only",
+                          "-o", str(asm), src], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    text = asm.read_text()
+    kernels = re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", text, flags=re.S)
+    assert len(kernels) > 100
+    spilled = {n: int(b) for n, b in kernels if int(b) > 0}
+    allowed = {n for n in spilled if "conv_cc" in n and "ELb1ELi" in n and spilled[n] <= 32}   # BIG variants
+    assert set(spilled) == allowed, {n: b for n, b in spilled.items() if n not in allowed}
+    assert text.count("v_mfma_f32_32x32x2") > 1000 and text.count("v_mfma_f32_16x16x4") > 50
+
+
 def test_precision_names_are_validated_before_any_device_call():
     from dynamics_aware_diffusion_amd import _engine
     assert _engine.PRECISIONS == {"fp32": 0, "f16x3": 1}
