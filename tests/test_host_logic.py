@@ -101,17 +101,17 @@ def test_debug_hooks_are_per_model():
         assert lib.dad_workspace_bytes(h, batch, C.byref(n)) == 0
         return n.value
 
-    # batch 16 is beyond the small-batch kernels: its scratch is the grid split-K slabs
-    base = ws(b, 16)
-    assert ws(a, 16) == base
+    # batch 32 is beyond the small-batch kernels: its scratch is the grid split-K slabs
+    base = ws(b, 32)
+    assert ws(a, 32) == base
     assert lib.dad_debug_set_tile(a, 99) == 0              # heuristic tiles, grid split-K off
-    assert ws(a, 16) < base                                # no split-K slabs any more
-    assert ws(b, 16) == base                               # the other model did not notice
+    assert ws(a, 32) < base                                # no split-K slabs any more
+    assert ws(b, 32) == base                               # the other model did not notice
     assert lib.dad_debug_set_option(a, b"split_target", 64) == 0
     assert lib.dad_debug_set_option(a, b"no_such_option", 1) == -1
     assert b"no_such_option" in lib.dad_last_error()
     assert lib.dad_debug_set_tile(a, -1) == 0
-    assert ws(a, 16) < base and ws(b, 16) == base          # split target 64 < 256: smaller slabs
+    assert ws(a, 32) < base and ws(b, 32) == base          # split target 64 < 256: smaller slabs
     # the small-batch (consumer-combine) kernels are a per-model switch as well
     one = ws(b, 1)
     assert lib.dad_debug_set_option(a, b"cc", 0) == 0 and lib.dad_debug_set_option(a, b"split_target", 256) == 0
