@@ -185,6 +185,17 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// 16-byte WRITE-THROUGH store (sc1): the bytes leave the XCD's L2 with the store itself, so a
+// hand-off to a workgroup on another XCD needs no release fence (buffer_wbl2) afterwards — only
+// every storing wave's s_waitcnt vmcnt(0) in front of the signal (MI355X_MICROARCH.md, visibility:
+// "publish-large": 8.2 -> 3.0 us for 64 KB per workgroup).  An asm store is invisible to hipcc's
+// vmcnt bookkeeping: the explicit s_waitcnt after the stores is part of the recipe.
+__device__ __forceinline__ void store_f4_sc1(float* p, const float4 v) {
+    typedef float __attribute__((ext_vector_type(4))) f4;
+    const f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
 // Activation rows in LDS and bank conflicts.  A wave's ds_read_b128 is served in four groups of
 // 16 lanes; a group is conflict-free when its lanes hit 16 different 16-byte slots of the 256-byte
 // bank row.  Lane n reads row  s*SEG + l  (sample s, position l), rows are an odd number of slots
@@ -745,22 +756,20 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     if (p.kslices > 1) {
         // Grid-level split-K: every block of the tile parks its partial tile in HBM; the block
         // that draws the last ticket adds all of them in slice order (bit-reproducible whichever
-        // block is last) and goes on to the epilogue alone.  Placement-independent hand-off:
-        // plain stores -> every wave drains -> barrier -> one agent-scope release -> ticket;
-        // the reducer takes one agent-scope acquire before any slab load (cdna guide, G16).
+        // block is last) and goes on to the epilogue alone.  Placement-independent hand-off
+        // (cdna guide G16, recipe R1): write-through (sc1) slab stores -> every wave drains ->
+        // barrier -> ticket (agent-scope atomic; no release fence: nothing is left dirty in L2);
+        // the reducer takes one agent-scope acquire before any slab load.
         const int KS = p.kslices;
         float* mine = p.slab + ((long)tile * KS + kb) * (BN * BM);
 #pragma unroll
         for (int k = 0; k < F4PL; ++k)
             if (eoff[k] >= 0)                         // rows of samples that exist (small batches)
-                *reinterpret_cast<float4*>(mine + erow[k] * BM + ecol[k]) =
-                    make_float4(y[k][0], y[k][1], y[k][2], y[k][3]);
+                store_f4_sc1(mine + erow[k] * BM + ecol[k], make_float4(y[k][0], y[k][1], y[k][2], y[k][3]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem + SK * ECOPY + 32);
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned ticket = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT);
             const unsigned last = ticket == (unsigned)(KS - 1);
