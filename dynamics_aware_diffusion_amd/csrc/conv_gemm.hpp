@@ -787,10 +787,20 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         for (int k = 0; k < F4PL; ++k) {
             if (eoff[k] < 0) continue;                // padding rows keep their (unused) partials
             const float* q = base + erow[k] * BM + ecol[k];
-            float4 v = *reinterpret_cast<const float4*>(q);
-            for (int c = 1; c < KS; ++c) {
-                const float4 u = *reinterpret_cast<const float4*>(q + (long)c * (BN * BM));
-                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            float4 v = ldg4(q);
+            // eight slabs per round trip (a one-at-a-time loop paid a full memory latency per slab:
+            // 32 slices = 32 round trips in the reducer of a wide layer at batch 1); slabs past
+            // the end re-read the last one and are weighted 0 — same sums, slice order kept
+            for (int c0 = 1; c0 < KS; c0 += 8) {
+                float4 u[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) u[j] = ldg4(q + (long)min(c0 + j, KS - 1) * (BN * BM));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float mj = c0 + j < KS ? 1.0f : 0.0f;
+                    v.x = fmaf(u[j].x, mj, v.x); v.y = fmaf(u[j].y, mj, v.y);
+                    v.z = fmaf(u[j].z, mj, v.z); v.w = fmaf(u[j].w, mj, v.w);
+                }
             }
             y[k][0] = v.x; y[k][1] = v.y; y[k][2] = v.z; y[k][3] = v.w;
         }
