@@ -119,6 +119,56 @@ if x3trace:
         json.dump(cur, open(tpath, "w"), indent=1)
     summary["f16x3"] = x3
 
+# ---- the other BASELINE configurations: per-kernel averages and HBM traffic per denoise step
+def pmc_all(dirname, counter):
+    f = one(f"{dirname}_*/**/*_counter_collection.csv")
+    if not f:
+        return None
+    tot = 0.0
+    for r in csv.DictReader(open(f)):
+        if "dad::" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            tot += float(r["Counter_Value"])
+    return tot
+
+
+others = {}
+for arch, batch, workload in (("halfcheetah", 128, "halfcheetah_b128"), ("door", 128, "door_b128"),
+                              ("pointmaze", 1, "pointmaze_b1")):
+    tag2 = f"{arch}_b{batch}"
+    tr = one(f"trace_{tag2}_*/**/*_kernel_trace.csv")
+    if not tr:
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(tr)):
+        if "dad::" in r["Kernel_Name"]:
+            a = agg[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    steps = sum(n for k, (n, t) in agg.items() if "final_" in k)
+    conv = [(n, t) for k, (n, t) in agg.items() if "conv_" in k]
+    entry = {"command": f"python3 profiles/pmc_target.py --arch {arch} --batch {batch} --denoise-steps 20",
+             "denoise_steps_traced": steps,
+             "conv_launches_per_denoise_step": sum(n for n, _ in conv) / max(1, steps),
+             "conv_avg_us": sum(t for _, t in conv) / max(1, sum(n for n, _ in conv)),
+             "all_kernels_us_per_denoise_step": sum(t for _, (n, t) in agg.items()) / max(1, steps),
+             "kernels_us": {k: {"calls": n, "avg_us": t / n} for k, (n, t) in agg.items()}}
+    st = one(f"trace_{tag2}_*/**/*_kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(here, f"{tag}_kernel_stats_{tag2}.csv"))
+    fe, wr = pmc_all(f"fetch_{tag2}", "FETCH_SIZE"), pmc_all(f"write_{tag2}", "WRITE_SIZE")
+    if fe is not None and wr is not None and steps:
+        nconv = max(1, sum(n for n, _ in conv))
+        per_step = (2.0 * fe + wr) * 1024.0 / steps
+        entry["hbm_bytes_per_denoise_step"] = per_step
+        entry["hbm_bytes_per_conv_launch"] = (2.0 * fe + wr) * 1024.0 / nconv
+        tpath = os.path.join(here, "traffic.json")
+        cur = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        cur[workload] = entry["hbm_bytes_per_conv_launch"]
+        json.dump(cur, open(tpath, "w"), indent=1)
+    others[tag2] = entry
+if others:
+    summary["other_configs"] = others
+
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj) and os.path.getsize(bj):
     summary["bench_line"] = json.loads(open(bj).read().strip().splitlines()[-1])
