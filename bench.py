@@ -290,7 +290,10 @@ def main() -> None:
             return {
                 "bound": "hbm", "kernel": "whole denoise step (weight stream, launch-latency bound)",
                 "achieved": hbm_floor / step_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": hbm_floor / step_s / (PEAK_HBM_GBS * 1e9), "traffic": None,
+                "frac": hbm_floor / step_s / (PEAK_HBM_GBS * 1e9),
+                # HBM bytes per denoise step from the committed PMC pass (per conv launch x launches)
+                "traffic": None if traffic is None else traffic * launches / diff_min(T),
+                "traffic_source": mfma["traffic_source"],
                 "algorithmic_bytes_per_denoise_step": hbm_floor, "us_per_denoise_step": step_s * 1e6,
                 "conv_gemm": mfma,
             }

@@ -594,3 +594,29 @@ def test_random_architectures_both_small_batch_families(arch, dev):
         torch.cuda.synchronize()
         assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP, small
         assert max_abs(xl.cpu().numpy(), want_loop.numpy()) <= TOL_LOOP, small
+
+
+def test_small_batch_projected_loop_graph_equals_eager(dev):
+    """Consumer-combine kernels + in-loop projection + hipGraph replay at batch 3: the replayed
+    graph (captured once, replayed with a new seed) equals eager launches bit for bit."""
+    from tests.test_hip_parity import _double_integrator_policy
+    diff = build("tiny", 20, "cosine", dev)
+    diff.sampler_rng = "philox"
+    cond = {0: torch.from_numpy(cases.loop_condition("smallproj", "tiny")).to(dev)}
+    try:
+        outs = {}
+        for graph in (False, True, True):
+            diff.use_graph = graph
+            pol = _double_integrator_policy(diff, "linear", 0.7, dev, project_during_sampling=True)
+            for seed in (5, 6):
+                diff.seed = seed
+                x = pol.sample_loop(batch_size=3, conditions=cond)
+                torch.cuda.synchronize()
+                outs.setdefault((graph, seed), []).append(x.cpu().numpy().copy())
+        for seed in (5, 6):
+            assert np.array_equal(outs[(False, seed)][0], outs[(True, seed)][0])
+            assert np.array_equal(outs[(True, seed)][0], outs[(True, seed)][1])
+        assert not np.array_equal(outs[(True, 5)][0], outs[(True, 6)][0])
+    finally:
+        diff.use_graph = False
+        diff.sampler_rng = "torch"
