@@ -441,8 +441,12 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
     if (lds > dad::kLdsBytes)
         return fail(DAD_E_INVALID, "final 1x1 conv does not fit LDS (td=%d, dim=%d)", c.transition_dim, c.dim);
     const long N = (long)batch * c.horizon;
-    hipLaunchKernelGGL(dad::final_posterior_kernel,
-                       dim3((unsigned)((N + dad::FINAL_COLS - 1) / dad::FINAL_COLS)), dim3(256), lds, st, p);
+    // columns of the transition are spread over gridDim.y when the row tiles alone leave CUs idle
+    const long row_tiles = (N + dad::FINAL_COLS - 1) / dad::FINAL_COLS;
+    const int jg = 256 / dad::FINAL_COLS;
+    const long col_groups = (c.transition_dim + jg - 1) / jg;
+    const long gy = std::max(1L, std::min(col_groups, 512 / row_tiles));
+    hipLaunchKernelGGL(dad::final_posterior_kernel, dim3((unsigned)row_tiles, (unsigned)gy), dim3(256), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;
 }

@@ -116,8 +116,14 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
         if (n0 + row < N) v = *reinterpret_cast<const float4*>(p.act + (n0 + row) * dim + q * 4);
         *reinterpret_cast<float4*>(tile + row * rs + q * 4) = v;
     }
-    for (int i = threadIdx.x; i < td * dq; i += blockDim.x)
-        *reinterpret_cast<float4*>(wl + i * 4) = *reinterpret_cast<const float4*>(p.w + i * 4);
+    // blockIdx.y owns the output columns j with (j / JG) % gridDim.y == blockIdx.y: wide transitions
+    // (and short grids) spread their columns over more blocks; each block stages only its own rows
+    constexpr int JG = 256 / FINAL_COLS;
+    for (int i = threadIdx.x; i < td * dq; i += blockDim.x) {
+        const int j = i / dq;
+        if ((j / JG) % (int)gridDim.y == (int)blockIdx.y)
+            *reinterpret_cast<float4*>(wl + i * 4) = *reinterpret_cast<const float4*>(p.w + i * 4);
+    }
     for (int i = threadIdx.x; i < td; i += blockDim.x) bl[i] = p.bias[i];
     __syncthreads();
 
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
     const int b = (int)(n / p.H);
     const int l = (int)(n - (long)b * p.H);
     const float* arow = tile + col * rs;
-    for (int j = jg; j < td; j += 256 / FINAL_COLS) {
+    for (int j = (int)blockIdx.y * JG + jg; j < td; j += JG * (int)gridDim.y) {
         const float* wr = wl + j * dim;
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;       // four chains, summed pairwise
         for (int c = 0; c < dim; c += 4) {
