@@ -32,4 +32,16 @@ DAD_HD inline size_t conv_lds_floats(int BM, int BN, int KC, int taps, int Lin, 
     return k > epi ? k : epi;
 }
 
+// conv_ccw.hpp (wide small-batch convs).  K phase: X rows with halo [XROWS][slice + 4], the additive
+// terms [rows][slice + 4], gamma / beta [2][slice], pair statistics; afterwards the exchange tile.
+constexpr int kCcwMaxPairs = 64;         // (sample, group) pairs of one block's input slice
+DAD_HD inline size_t ccw_lds_floats(int slice_ch, int taps, int Lin, int Lout, int nr) {
+    const int spt = nr / Lout;
+    const size_t xs = slice_ch + 4;
+    const size_t k = (size_t)spt * (Lin + 2 * (taps / 2)) * xs + (size_t)spt * Lin * xs + 2 * (size_t)slice_ch +
+                     2 * kCcwMaxPairs;
+    const size_t e = (size_t)2 * 8 * nr * 36;
+    return k > e ? k : e;
+}
+
 }  // namespace dad

@@ -23,6 +23,7 @@
 #include "conv_gemm.hpp"
 #include "pointwise.hpp"
 #include "conv_cc.hpp"
+#include "conv_ccw.hpp"
 
 using namespace dadhost;
 
@@ -185,6 +186,22 @@ const void* cc_kernel(int taps, bool ride, bool big, int rows) {
     return big ? cc_kernel_t<true, 32>(taps, ride) : cc_kernel_t<false, 32>(taps, ride);
 }
 
+// conv_ccw.hpp instantiations: (taps, this launch carries a riding 1x1 conv, an input has ride slabs,
+// rows per tile)
+template <bool RIDE, int NR>
+const void* ccw_kernel_t(int taps, bool res) {
+    if (taps == 5) return res ? (const void*)dad::conv_ccw<5, 1, true, RIDE, NR> : (const void*)dad::conv_ccw<5, 1, false, RIDE, NR>;
+    if (res) return nullptr;
+    if (taps == 3) return (const void*)dad::conv_ccw<3, 2, false, RIDE, NR>;
+    if (taps == 2) return (const void*)dad::conv_ccw<2, 1, false, RIDE, NR>;
+    if (taps == 1) return (const void*)dad::conv_ccw<1, 1, false, RIDE, NR>;
+    return nullptr;
+}
+const void* ccw_kernel(int taps, bool res, bool ride_in, int rows) {
+    if (rows == 16) return ride_in ? ccw_kernel_t<true, 16>(taps, res) : ccw_kernel_t<false, 16>(taps, res);
+    return ride_in ? ccw_kernel_t<true, 32>(taps, res) : ccw_kernel_t<false, 32>(taps, res);
+}
+
 // Every kernel may use up to the full 160 KiB of LDS; the dynamic-LDS limit is a per-device
 // function attribute, raised once per device (not lazily per launch, so that nothing but launches
 // happens under hipGraph capture).
@@ -205,6 +222,12 @@ int configure_kernels() {
             for (int big = 0; big < 2; ++big)
                 for (int rows : {16, 32})
                     if (const void* k = cc_kernel(taps, ride != 0, big != 0, rows))
+                        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    for (int taps : {5, 3, 2, 1})
+        for (int res = 0; res < 2; ++res)
+            for (int ride = 0; ride < 2; ++ride)
+                for (int rows : {16, 32})
+                    if (const void* k = ccw_kernel(taps, res != 0, ride != 0, rows))
                         HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dad::kLdsBytes));
@@ -313,6 +336,9 @@ dad::CcSrc cc_source(dad_model* m, const CcPlan& cc, const CcInput& in, int chan
     else if (qo.res_kind == 3) {
         const CcOp& r = cc.ops[qo.res_ride];
         s.rslab = slabs + r.orslab; s.nrs = r.kslices; s.rbias = m->plan.convs[qo.res_ride].d_rbias;
+    } else if (qo.res_kind == 4) {                        // the block's stand-alone 1x1 residual conv
+        const CcOp& r = cc.ops[qo.res_ride];
+        s.rslab = slabs + r.oslab; s.nrs = r.kslices; s.rbias = m->plan.convs[qo.res_ride].d_bias;
     }
     s.mat = buf(in.buf);
     return s;
@@ -339,11 +365,16 @@ int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float*
     const bool big = p.src0.nsl > dad::CC_MAX_SLABS || p.src0.nrs > dad::CC_MAX_SLABS ||
                      p.src1.nsl > dad::CC_MAX_SLABS || p.src1.nrs > dad::CC_MAX_SLABS;
     const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, big, o.tile_rows) : nullptr;
+    if (o.wide) {
+        if (big) return fail(DAD_E_INVALID, "wide small-batch conv %s: more than %d partial slabs", op.name.c_str(), dad::CC_MAX_SLABS);
+        kern = ccw_kernel(op.taps, op.ride, p.src0.rslab != nullptr || p.src1.rslab != nullptr, o.tile_rows);
+    }
     if (!kern) return fail(DAD_E_INVALID, "no small-batch kernel for %s (taps=%d stride=%d)", op.name.c_str(), op.taps, op.stride);
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;
     if (trace)
         fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d cc slice=%d kslices=%d ntiles=%d%s\n", op.name.c_str(), batch,
                 op.M, op.taps, op.cin0 + op.cin1, op.Lout, o.slice_ch, o.kslices, o.ntiles, op.ride ? " +res1x1" : "");
+    if (trace && o.wide) fprintf(stderr, "[dad]   (wide: %d-row tiles, %zu B LDS)\n", o.tile_rows, o.lds_bytes);
 #ifdef DAD_STAMPS
     p.stamps = g_stamps ? g_stamps + (size_t)i * 16 : nullptr;
 #endif

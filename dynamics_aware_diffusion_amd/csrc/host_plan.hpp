@@ -698,8 +698,11 @@ inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g)
 // host: which launches exist, their K slices, where their partial slabs live, and for every input
 // whether it is read finished (external trajectory / already materialised) or in pieces.
 constexpr int kCcMaxSlabs = 16;          // slabs a consumer adds (8 per round trip)
-constexpr int kCcMaxSlice = 64;          // channels per K slice: weight tile + input slice stay well inside
-                                         // LDS and 6 float4 of weights per thread
+constexpr int kCcMaxSlice = 64;          // channels per K slice of conv_cc: weight tile + input slice stay well
+                                         // inside LDS and 6 float4 of weights per thread
+constexpr int kCcwMaxSlabs = 8;          // conv_ccw (wide layers): slabs per input, one round trip
+using dad::kCcwMaxPairs;
+constexpr int kCcwMaxPair = 2048;        // elements of one pair (8 float4 per lane)
 struct CcInput {
     int kind = 0;            // 0 none, 1 external trajectory, 2 finished tensor in a plan buffer, 3 in pieces
     int buf = -1;            // kind 2 / 3: the tensor's activation buffer (kind 3: where it is materialised)
@@ -707,6 +710,7 @@ struct CcInput {
 };
 struct CcOp {
     bool launched = false;   // false: the op does not exist in this form (riding 1x1 conv)
+    bool wide = false;       // conv_ccw.hpp: weights streamed through registers, K slices of up to 1024 channels
     int slice_ch = 0, kslices = 0, ntiles = 0;
     int tile_rows = 32;      // GEMM rows per tile: 16 for layers of at most 16 positions (16x16x4 MFMAs)
     long oslab = 0, orslab = -1;       // float offsets into the CC slab region
@@ -714,7 +718,8 @@ struct CcOp {
     size_t lds_bytes = 0;
     CcInput in0, in1;
     // how this conv's OUTPUT is finished by whoever consumes it
-    int res_kind = 0;        // 0 none, 1 external trajectory, 2 finished tensor (buffer res_buf), 3 ride of conv res_ride
+    int res_kind = 0;        // 0 none, 1 external trajectory, 2 finished tensor (buffer res_buf),
+                             // 3 ride of conv res_ride, 4 the stand-alone 1x1 conv res_ride, still in pieces
     int res_buf = -1, res_ride = -1;
 };
 struct CcPlan {
@@ -731,8 +736,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 32 ||
         (long)batch * c.horizon > m.cc_max_rows)
         return P;
-    for (const ConvOp& op : convs)
-        if (op.kc != 16 || op.cat0 >= 0 || op.bdir || op.x3 || (!op.rname.empty() && !op.ride)) return P;
+    for (const ConvOp& op : convs)      // weight images in 16-channel granules only
+        if ((op.kc != 16 && !op.bdir) || op.cat0 >= 0 || op.x3 || (!op.rname.empty() && !op.ride)) return P;
     P.ops.resize(convs.size());
     std::vector<int> owner(m.plan.bufs.size(), -1);     // buffer -> conv whose output it holds
     std::vector<char> materialised(convs.size(), 0);
@@ -754,30 +759,74 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             return true;
         };
         if (!input(op.src0, o.in0) || !input(op.src1, o.in1)) return P;
-        // K slices: whole GroupNorm groups of the tensor being finished, at most kCcMaxSlabs slices
+        if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return P;
+        // K slices: whole GroupNorm groups of the tensor being finished
         const int cin = op.cin0 + op.cin1;
-        int need = 32;
+        int need = 32, max_slabs_in = 0;
+        long max_pair = 0;
         for (const CcInput* in : {&o.in0, &o.in1})
-            if (in->kind == 3 && !convs[in->producer].norm.empty())
-                need = std::max(need, convs[in->producer].cout / 8);
+            if (in->kind == 3) {
+                const ConvOp& q = convs[in->producer];
+                const CcOp& qo = P.ops[in->producer];
+                max_slabs_in = std::max(max_slabs_in, qo.kslices);
+                if (qo.res_kind >= 3) max_slabs_in = std::max(max_slabs_in, P.ops[qo.res_ride].kslices);
+                if (!q.norm.empty()) {
+                    need = std::max(need, q.cout / 8);
+                    max_pair = std::max(max_pair, (long)(q.cout / 8) * op.Lin);
+                    if (need % (q.cout / 8) != 0) return P;          // slices must hold whole groups
+                }
+            }
         int slice = need;
         while ((cin + slice - 1) / slice > 8 && slice < kCcMaxSlice) slice *= 2;     // 8 slabs: one round trip
         while ((cin + slice - 1) / slice > kCcMaxSlabs) slice *= 2;
-        if (slice > kCcMaxSlice) return P;
+        // conv_cc keeps the whole weight slice in LDS and normalises a pair in one wave's registers;
+        // anything wider goes to conv_ccw (weights streamed global -> registers)
+        o.wide = slice > kCcMaxSlice || max_pair > 1024 || op.bdir || op.kind == CONV_1X1;   // (conv_cc has no 1x1 form)
+        if (!o.wide) {
+            if (slice % 32 != 0) return P;
+            // 16-row tiles (16x16x4 MFMAs, half the padded rows) as long as the layer still fits one wave
+            // of blocks; beyond that the extra N tiles only re-stream the weights
+            o.tile_rows = 32;
+            if (op.Lout <= 16) {
+                const int ks = (cin + slice - 1) / slice;
+                const long blocks16 = (long)((batch + 16 / op.Lout - 1) / (16 / op.Lout)) * (op.M / 32) * ks;
+                if (blocks16 <= 256) o.tile_rows = 16;
+            }
+        } else {
+            if (op.src0 == -2 || (op.cin0 & 3) || (op.cin1 & 3) || max_slabs_in > kCcwMaxSlabs ||
+                max_pair > kCcwMaxPair)
+                return P;
+            // tile rows: 16 when that needs no more N tiles than 32 would (batch 1 / 2 on short levels)
+            o.tile_rows = 32;
+            if (op.Lout <= 16 && (batch + 16 / op.Lout - 1) / (16 / op.Lout) == (batch + 32 / op.Lout - 1) / (32 / op.Lout))
+                o.tile_rows = 16;
+            const int spt_w = o.tile_rows / op.Lout;
+            const long nt = (batch + spt_w - 1) / spt_w;
+            auto fits = [&](int sl) {
+                return dad::ccw_lds_floats(sl, op.taps, op.Lin, op.Lout, o.tile_rows) * sizeof(float) <= dad::kLdsBytes;
+            };
+            slice = need;
+            while (slice % 32 != 0) slice += need;
+            while ((cin + slice - 1) / slice > kCcwMaxSlabs) slice *= 2;
+            // fewer, fatter slices while the chip stays covered: every slab is re-read by all the M tiles
+            // of its consumer
+            while ((long)((cin + 2 * slice - 1) / (2 * slice)) * (op.M / 32) * nt >= 256 && 2 * slice <= cin && fits(2 * slice) &&
+                   (op.cin1 == 0 || op.cin0 % (2 * slice) == 0))
+                slice *= 2;
+            if (!fits(slice)) return P;
+            int min_cpg = slice;
+            for (const CcInput* in : {&o.in0, &o.in1})
+                if (in->kind == 3 && !convs[in->producer].norm.empty())
+                    min_cpg = std::min(min_cpg, convs[in->producer].cout / 8);
+            if ((long)spt_w * (slice / min_cpg) > kCcwMaxPairs) return P;
+        }
         if (op.cin1 > 0 && op.cin0 % slice != 0) return P;     // a slice may not straddle the concat
         o.slice_ch = slice;
         o.kslices = (cin + slice - 1) / slice;
         if ((long)o.kslices * slice > op.cin_pad) return P;    // weight image too short for whole slices
-        if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return P;
-        // a (sample, group) pair of the output is normalised by one wave in registers: <= 1024 elements
-        if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > 1024) return P;
-        // 16-row tiles (16x16x4 MFMAs, half the padded rows) as long as the layer still fits one wave
-        // of blocks; beyond that the extra N tiles only re-stream the weights
-        o.tile_rows = 32;
-        if (op.Lout <= 16) {
-            const long blocks16 = (long)((batch + 16 / op.Lout - 1) / (16 / op.Lout)) * (op.M / 32) * o.kslices;
-            if (blocks16 <= 256) o.tile_rows = 16;
-        }
+        // a (sample, group) pair of the output is normalised by its consumer: conv_cc / final_cc take at
+        // most 1024 elements per pair, conv_ccw 2048 (checked again where the consumer is planned)
+        if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > kCcwMaxPair) return P;
         const int spt = o.tile_rows / op.Lout;
         o.ntiles = (batch + spt - 1) / spt;
         o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;
@@ -785,8 +834,10 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         o.oslab = off;
         off += (long)o.kslices * o.out_rows * o.out_cols;
         if (op.ride) { o.orslab = off; off += (long)o.kslices * o.out_rows * o.out_cols; }
-        // the exchange tile needs 2 * 8 * 32 * 36 floats; operands XROWS + weight rows of slice + 4
-        {
+        if (o.wide) {
+            o.lds_bytes = dad::ccw_lds_floats(slice, op.taps, op.Lin, op.Lout, o.tile_rows) * sizeof(float);
+        } else {
+            // the exchange tile needs 2 * 8 * 32 * 36 floats; operands XROWS + weight rows of slice + 4
             const size_t xs = slice + 4;
             const size_t k = (size_t)spt * (op.Lin + 2 * (op.taps / 2)) * xs + (size_t)op.wtaps() * 32 * xs;
             const size_t e = (size_t)2 * 8 * o.tile_rows * 36;
@@ -799,12 +850,18 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             const int q = owner[op.res];
             if (q <= -2) { o.res_kind = 3; o.res_ride = -2 - q; }
             else if (q >= 0 && materialised[q]) { o.res_kind = 2; o.res_buf = op.res; }
-            else return P;                               // residual not finished yet: not a plan we know
+            else if (q >= 0 && convs[q].kind == CONV_1X1 && convs[q].norm.empty() && P.ops[q].launched) {
+                o.res_kind = 4; o.res_ride = q;          // the block's own 1x1 residual conv, still in pieces
+            } else return P;                             // residual not finished yet: not a plan we know
         }
         owner[op.dst] = (int)i;
     }
     P.final_producer = owner[m.plan.final_act];
     if (P.final_producer < 0 || materialised[P.final_producer]) return P;
+    {   // final_cc_kernel normalises a pair in one wave's registers
+        const ConvOp& f = convs[P.final_producer];
+        if ((long)(f.cout / 8) * f.Lout > 1024 || P.ops[P.final_producer].kslices > kCcMaxSlabs) return P;
+    }
     P.slab_floats = off;
     P.ok = true;
     return P;

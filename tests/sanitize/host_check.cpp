@@ -225,14 +225,24 @@ static void check_arch(const Arch& a, int precision) {
             const ConvOp& op = P.convs[i];
             const CcOp& o = cc.ops[i];
             if (!o.launched) { CHECK(op.rider_of >= 0 && P.convs[op.rider_of].ride, "%s not launched", op.name.c_str()); continue; }
-            CHECK(o.kslices >= 1 && o.kslices <= kCcMaxSlabs && o.slice_ch % 32 == 0 && o.slice_ch <= kCcMaxSlice,
+            CHECK(o.kslices >= 1 && o.kslices <= (o.wide ? kCcwMaxSlabs : kCcMaxSlabs) && o.slice_ch % 32 == 0 &&
+                  (o.wide || o.slice_ch <= kCcMaxSlice),
                   "%s: slices %d x %d", op.name.c_str(), o.kslices, o.slice_ch);
             CHECK((long)o.kslices * o.slice_ch >= op.cin0 + op.cin1 && (long)o.kslices * o.slice_ch <= op.cin_pad,
                   "%s: slices do not cover the input channels", op.name.c_str());
             CHECK(op.cin1 == 0 || op.cin0 % o.slice_ch == 0, "%s: slice straddles the concat", op.name.c_str());
             CHECK(o.lds_bytes <= dad::kLdsBytes, "%s: CC LDS %zu", op.name.c_str(), o.lds_bytes);
-            CHECK((size_t)(o.slice_ch / 16) * op.wtaps() * 128 <= (size_t)6 * 512, "%s: weight staging registers", op.name.c_str());
-            CHECK(o.kslices <= 8 || o.slice_ch == kCcMaxSlice, "%s: more than 8 slabs below the widest slice", op.name.c_str());
+            if (o.wide) {
+                // conv_ccw.hpp's contract: 16-channel granules, channel counts in float4, LDS sized by its formula
+                CHECK((op.kc == 16 || op.bdir) && op.cin0 % 4 == 0 && op.cin1 % 4 == 0 && op.src0 != -2,
+                      "%s: wide conv on an input it cannot stage", op.name.c_str());
+                CHECK(o.lds_bytes == dad::ccw_lds_floats(o.slice_ch, op.taps, op.Lin, op.Lout, o.tile_rows) * sizeof(float),
+                      "%s: wide LDS size", op.name.c_str());
+            } else {
+                CHECK(op.kind != CONV_1X1, "%s: conv_cc has no 1x1 form", op.name.c_str());
+                CHECK((size_t)(o.slice_ch / 16) * op.wtaps() * 128 <= (size_t)6 * 512, "%s: weight staging registers", op.name.c_str());
+                CHECK(o.kslices <= 8 || o.slice_ch == kCcMaxSlice, "%s: more than 8 slabs below the widest slice", op.name.c_str());
+            }
             CHECK((o.tile_rows == 16 || o.tile_rows == 32) && o.tile_rows % op.Lout == 0 &&
                   o.ntiles * (o.tile_rows / op.Lout) >= B, "%s: tiles do not cover the batch", op.name.c_str());
             const long n = (long)o.kslices * o.out_rows * o.out_cols;
@@ -248,10 +258,26 @@ static void check_arch(const Arch& a, int precision) {
                     if (!q.norm.empty()) CHECK(o.slice_ch % (q.cout / 8) == 0, "%s: slice splits a GroupNorm group", op.name.c_str());
                     const CcOp& qo = cc.ops[in->producer];
                     if (qo.res_kind == 3) CHECK(cc.ops[qo.res_ride].orslab >= 0 && qo.res_ride < in->producer, "%s: ride source", op.name.c_str());
+                    if (qo.res_kind == 4) CHECK(cc.ops[qo.res_ride].launched && P.convs[qo.res_ride].kind == CONV_1X1 && qo.res_ride < in->producer,
+                                                "%s: residual conv source", op.name.c_str());
+                    const long pair = q.norm.empty() ? 0 : (long)(q.cout / 8) * op.Lin;
+                    const int spt = o.tile_rows / op.Lout;
+                    if (o.wide) {
+                        CHECK(qo.kslices <= kCcwMaxSlabs && (qo.res_kind < 3 || cc.ops[qo.res_ride].kslices <= kCcwMaxSlabs),
+                              "%s: wide conv fed more than %d slabs", op.name.c_str(), kCcwMaxSlabs);
+                        CHECK(pair <= kCcwMaxPair, "%s: pair of %ld elements", op.name.c_str(), pair);
+                        if (!q.norm.empty()) CHECK((long)spt * (o.slice_ch / (q.cout / 8)) <= kCcwMaxPairs, "%s: pairs per block", op.name.c_str());
+                    } else {
+                        CHECK(pair <= 1024, "%s: conv_cc normalises at most 1024 elements per pair (%ld)", op.name.c_str(), pair);
+                    }
                 }
             }
         }
         CHECK(cc.final_producer >= 0 && !finished[cc.final_producer], "final conv output already finished");
+        if (cc.final_producer >= 0) {
+            const ConvOp& f = P.convs[cc.final_producer];
+            CHECK((long)(f.cout / 8) * f.Lout <= 1024, "final_cc normalises at most 1024 elements per pair");
+        }
         std::sort(spans.begin(), spans.end());
         for (size_t k = 0; k + 1 < spans.size(); ++k) CHECK(spans[k].second <= spans[k + 1].first, "CC slabs overlap");
         if (!spans.empty()) CHECK(spans.front().first >= 0 && spans.back().second <= cc.slab_floats, "CC slabs outside their region");
