@@ -57,9 +57,17 @@ WORKLOADS = {
     "door_b128": ("door", 128, 1000, 5,
                   "AdroitHand door expert-v2, H=32 dim=256 mults(1,2,4,8) T=1000 batch=128/GPU "
                   "(config 5 = 1024 plans sharded over 8 GPUs)"),
+    # not BASELINE configurations: the same batch-1 planning call (`get_action`) on the two wide
+    # architectures, where a denoise step is an HBM weight stream of 1.2 / 1.3 GB
+    "halfcheetah_b1": ("halfcheetah", 1, 1000, None,
+                       "HalfCheetah architecture, batch=1 (the get_action planning call; hipGraph replay)"),
+    "door_b1": ("door", 1, 1000, None,
+                "AdroitHand door architecture, batch=1 (the get_action planning call; hipGraph replay)"),
 }
-# the other BASELINE configurations timed after the headline, in this order
-EXTRA_CONFIGS = ["pointmaze_b1", "pointmaze_proj_t500_b256", "halfcheetah_b128", "door_b128"]
+# the other BASELINE configurations timed after the headline, in this order (+ the two batch-1
+# calls on the wide nets)
+EXTRA_CONFIGS = ["pointmaze_b1", "pointmaze_proj_t500_b256", "halfcheetah_b128", "door_b128",
+                 "halfcheetah_b1", "door_b1"]
 
 
 def parse_args():
@@ -440,7 +448,8 @@ def main() -> None:
                 # loops timed: the T=1000 nets take seconds per loop (one is enough), the short ones
                 # are repeated so that a single disturbed loop does not become the number
                 _, b_, T_, _, _ = WORKLOADS[name]
-                configs[name] = run_workload(name, 5 if b_ == 1 else (3 if T_ <= 500 else 1), 1, headline=False)
+                loops = (5 if T_ <= 100 else 2) if b_ == 1 else (3 if T_ <= 500 else 1)
+                configs[name] = run_workload(name, loops, 1, headline=False)
             except Exception as exc:               # noqa: BLE001
                 if dist is not None:
                     raise                          # ranks must stay in step: fail loudly

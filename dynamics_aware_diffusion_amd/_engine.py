@@ -81,6 +81,8 @@ ABI = {
     "dad_debug_read_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.POINTER(C.c_int32)]),
     "dad_debug_mish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dad_debug_small_batch_plan": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32)]),
     "dad_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_double)]),
@@ -366,6 +368,13 @@ class HipEngine:
             _check(self.lib, self.lib.dad_debug_read_table(self._h, TABLES[which], int(t),
                                                            out.data_ptr(), out.numel(), C.byref(width)))
         return out[:width.value].clone()
+
+    def small_batch_plan(self, batch: int):
+        """(conv launches through the consumer-combine kernels, how many of them are the
+        streamed-weight form for wide layers); (0, 0) when the batch takes the batch-256 kernels."""
+        n, w = C.c_int32(), C.c_int32()
+        _check(self.lib, self.lib.dad_debug_small_batch_plan(self._h, int(batch), C.byref(n), C.byref(w)))
+        return n.value, w.value
 
     def mish(self, x: torch.Tensor) -> torch.Tensor:
         """The conv epilogue's Mish applied to a device tensor (test hook)."""

@@ -580,14 +580,20 @@ __global__ __launch_bounds__(CC_THREADS) void final_cc_kernel(const FinalCcParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const int dq = dim >> 2;
-    for (int i = tid; i < td * dq; i += CC_THREADS)
-        *reinterpret_cast<float4*>(wl + i * 4) = ldg4(p.w + i * 4);
+    // blockIdx.y owns a contiguous range of output columns (wide transitions at batch 1 would
+    // otherwise leave the whole 1x1 conv to one CU)
+    const int jlo = (td * (int)blockIdx.y) / (int)gridDim.y, jhi = (td * ((int)blockIdx.y + 1)) / (int)gridDim.y;
+    for (int i = tid; i < (jhi - jlo) * dq; i += CC_THREADS)
+        *reinterpret_cast<float4*>(wl + i * 4) = ldg4(p.w + (long)jlo * dim + i * 4);
     for (int i = tid; i < td; i += CC_THREADS) bl[i] = p.bias[i];
     cc_build_input<false>(pp.src, tile, rs, b * H, H, H, H, 31 - __clz(H), H, 0, 0, dim, false, tid, lane, wave);
     __syncthreads();
-    for (int o = tid; o < H * td; o += CC_THREADS) {
-        const int l = o / td, j = o - l * td;
-        const float* wr = wl + j * dim;
+    // neighbouring lanes take neighbouring positions of one column: the tile rows have an odd
+    // 16-byte stride (conflict-free) and the weight row is a broadcast (the transposed mapping read
+    // td different weight rows, all on one bank)
+    for (int o = tid; o < H * (jhi - jlo); o += CC_THREADS) {
+        const int jj = o / H, l = o - jj * H, j = jlo + jj;
+        const float* wr = wl + jj * dim;
         const float* arow = tile + l * rs;
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;       // four chains, summed pairwise
         for (int c = 0; c < dim; c += 4) {

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
     asm volatile("" ::"s"(p.w), "s"(p.wtaps), "s"(p.cin0), "s"(p.cin1), "s"(p.M), "s"(p.B), "s"(p.Lin), "s"(p.Lout),
                  "s"(p.lshift), "s"(p.lshift_in), "s"(p.interleave), "s"(p.slice_ch), "s"(p.oslab), "s"(p.orslab),
                  "s"(p.out_rows));
+    CC_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
     float4 wq0[CCW_DEPTH], wq1[CCW_DEPTH];
 #pragma unroll
     for (int i = 0; i < CCW_DEPTH; ++i) wload(i, wq0[i], wq1[i]);
+    CC_STAMP(1);
 
     // ---- 3. finish the input slice into LDS ------------------------------------------------------
     // zero: halo rows, absent samples, columns past the staged channels
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
             *reinterpret_cast<float4*>(GBb + SL + 4 * t) = ldg4(src.beta + cs0 + 4 * t);
         }
     __syncthreads();
+    CC_STAMP(2);
     if (gn) {
         // statistics of every (sample, group) pair of the slice: one wave per pair, from LDS
         const int cpg = src.cpg, groups = nch / cpg, cqp = cpg >> 2;
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
         __syncthreads();
     }
 
+    CC_STAMP(3);
     // ---- 4. K loop: A fragments from LDS, B fragments from the rolling register ring ------------
     const int phase_shift = (TAPS == 2 && p.interleave && m0 >= (M >> 1)) ? 1 : 0;
     constexpr int ES = 36;
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
 #pragma unroll
     for (int i = 0; i < CCW_DEPTH; ++i)
         if (base + i < nU) unit(base + i, wq0[i], wq1[i]);
+    CC_STAMP(4);
     __syncthreads();                                   // all fragment reads done: LDS becomes the exchange tile
     if constexpr (NR == 32) {
 #pragma unroll
@@ -377,6 +382,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
         }
     }
     __syncthreads();
+    CC_STAMP(5);
     const int which = tid >> 8;                        // 0: the conv, 1: the riding 1x1 conv
     if (which == 1 && !RES) return;
     const int t8 = tid & 255;
@@ -404,6 +410,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
     }
     float* out = (which ? p.orslab : p.oslab) + (long)kb * p.out_rows * ocols + off;
     *reinterpret_cast<float4*>(out) = v;
+    CC_STAMP(6);
 }
 
 }  // namespace dad

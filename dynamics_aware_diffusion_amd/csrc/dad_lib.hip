@@ -464,7 +464,11 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         const size_t lds_cc = dad::final_cc_lds_floats(c.transition_dim, c.dim, c.horizon) * sizeof(float);
         if (lds_cc > dad::kLdsBytes)
             return fail(DAD_E_INVALID, "final 1x1 conv does not fit LDS (td=%d, dim=%d)", c.transition_dim, c.dim);
-        hipLaunchKernelGGL(dad::final_cc_kernel, dim3(batch), dim3(dad::CC_THREADS), lds_cc, st, fp);
+        // one block per (sample, group of output columns): enough columns per block to occupy its
+        // 512 threads once, as long as the grid stays within one wave of blocks
+        const int want = (c.horizon * c.transition_dim + dad::CC_THREADS - 1) / dad::CC_THREADS;
+        const int gy = std::max(1, std::min({want, c.transition_dim, 256 / std::max(batch, 1)}));
+        hipLaunchKernelGGL(dad::final_cc_kernel, dim3(batch, gy), dim3(dad::CC_THREADS), lds_cc, st, fp);
         HIP_TRY(hipGetLastError());
         return DAD_OK;
     }
@@ -862,6 +866,7 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value) {
     else if (key == "split_target") m->split_target = std::max(1, (int)value);
     else if (key == "cc") m->cc_enabled = value != 0;
     else if (key == "cc_max_rows") m->cc_max_rows = std::max(0, (int)value);
+    else if (key == "ccw_max_rows") m->ccw_max_rows = std::max(0, (int)value);
     else return fail(DAD_E_INVALID, "unknown option '%s'", name);
     return DAD_OK;
 }
@@ -893,6 +898,20 @@ int dad_debug_mish(const float* in, float* out, int64_t n, dad_stream_t stream) 
     hipLaunchKernelGGL(dad::mish_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, in, out, (long)n);
     HIP_TRY(hipGetLastError());
+    return DAD_OK;
+}
+
+int dad_debug_small_batch_plan(dad_model* m, int32_t batch, int32_t* launches_out, int32_t* wide_out) {
+    if (!m || batch <= 0) return fail(DAD_E_INVALID, "bad argument");
+    const CcPlan cc = cc_plan(*m, batch);
+    int launches = 0, wide = 0;
+    if (cc.ok)
+        for (const CcOp& o : cc.ops) {
+            launches += o.launched;
+            wide += o.launched && o.wide;
+        }
+    if (launches_out) *launches_out = launches;
+    if (wide_out) *wide_out = wide;
     return DAD_OK;
 }
 

@@ -134,6 +134,7 @@ struct HostModel {
     int split_target = 256;
     bool cc_enabled = true;                                    // small batches take the consumer-combine kernels
     int cc_max_rows = 512;                                     //   up to this many batch * horizon rows
+    int ccw_max_rows = 128;                                    //   the same for nets whose plan needs conv_ccw.hpp (wide layers)
                                                                //   (measured crossover: batch 16 at H = 32)
     std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo
 };
@@ -796,24 +797,31 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             if (op.src0 == -2 || (op.cin0 & 3) || (op.cin1 & 3) || max_slabs_in > kCcwMaxSlabs ||
                 max_pair > kCcwMaxPair)
                 return P;
-            // tile rows: 16 when that needs no more N tiles than 32 would (batch 1 / 2 on short levels)
+            // tile rows: 16 when that needs no more N tiles than 32 would (batch 1 / 2 on short levels),
+            // or when a 32-row tile of the narrowest admissible slice does not fit LDS
+            auto try_rows = [&](int rows) -> int {
+                auto fits = [&](int sl) {
+                    return dad::ccw_lds_floats(sl, op.taps, op.Lin, op.Lout, rows) * sizeof(float) <= dad::kLdsBytes;
+                };
+                const int spt_r = rows / op.Lout;
+                const long nt = (batch + spt_r - 1) / spt_r;
+                int sl = need;
+                while (sl % 32 != 0) sl += need;
+                while ((cin + sl - 1) / sl > kCcwMaxSlabs) sl *= 2;
+                // fewer, fatter slices while the chip stays covered: every slab is re-read by all the M
+                // tiles of its consumer
+                while ((long)((cin + 2 * sl - 1) / (2 * sl)) * (op.M / 32) * nt >= 256 && 2 * sl <= cin && fits(2 * sl) &&
+                       (op.cin1 == 0 || op.cin0 % (2 * sl) == 0))
+                    sl *= 2;
+                return fits(sl) ? sl : 0;
+            };
             o.tile_rows = 32;
             if (op.Lout <= 16 && (batch + 16 / op.Lout - 1) / (16 / op.Lout) == (batch + 32 / op.Lout - 1) / (32 / op.Lout))
                 o.tile_rows = 16;
+            slice = try_rows(o.tile_rows);
+            if (slice == 0 && o.tile_rows == 32 && op.Lout <= 16) { o.tile_rows = 16; slice = try_rows(16); }
+            if (slice == 0) return P;
             const int spt_w = o.tile_rows / op.Lout;
-            const long nt = (batch + spt_w - 1) / spt_w;
-            auto fits = [&](int sl) {
-                return dad::ccw_lds_floats(sl, op.taps, op.Lin, op.Lout, o.tile_rows) * sizeof(float) <= dad::kLdsBytes;
-            };
-            slice = need;
-            while (slice % 32 != 0) slice += need;
-            while ((cin + slice - 1) / slice > kCcwMaxSlabs) slice *= 2;
-            // fewer, fatter slices while the chip stays covered: every slab is re-read by all the M tiles
-            // of its consumer
-            while ((long)((cin + 2 * slice - 1) / (2 * slice)) * (op.M / 32) * nt >= 256 && 2 * slice <= cin && fits(2 * slice) &&
-                   (op.cin1 == 0 || op.cin0 % (2 * slice) == 0))
-                slice *= 2;
-            if (!fits(slice)) return P;
             int min_cpg = slice;
             for (const CcInput* in : {&o.in0, &o.in1})
                 if (in->kind == 3 && !convs[in->producer].norm.empty())
@@ -858,6 +866,11 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     }
     P.final_producer = owner[m.plan.final_act];
     if (P.final_producer < 0 || materialised[P.final_producer]) return P;
+    // the streamed-weight form re-reads the weights once per N tile: measured against the batch-256
+    // kernels it pays up to 4 plans of 32 positions (HalfCheetah 410 / 627 us per step at batch 1 / 4
+    // against 597 / 653; 973 against 683 at batch 6)
+    for (const CcOp& o : P.ops)
+        if (o.launched && o.wide && (long)batch * c.horizon > m.ccw_max_rows) return P;
     {   // final_cc_kernel normalises a pair in one wave's registers
         const ConvOp& f = convs[P.final_producer];
         if ((long)(f.cout / 8) * f.Lout > 1024 || P.ops[P.final_producer].kslices > kCcMaxSlabs) return P;

@@ -207,7 +207,8 @@ int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, doub
  * launch; 0 = always its own launch), "xswz" (LDS slot shifts), "xcd_order" (XCD-aware tile
  * order), "split_target" (blocks a split-K layer aims for), "cc" (small batches take the
  * consumer-combine kernels of csrc/conv_cc.hpp; 0 = always the batch-256 kernels), "cc_max_rows"
- * (largest batch * horizon that does).
+ * (largest batch * horizon that does), "ccw_max_rows" (the same bound for nets whose small-batch plan
+ * needs the streamed-weight kernels of csrc/conv_ccw.hpp: GroupNorm groups wider than 64 channels).
  * Results do not depend on these choices beyond fp32 summation order. */
 int dad_debug_set_tile(dad_model* m, int32_t cfg);
 int dad_debug_set_option(dad_model* m, const char* name, int32_t value);
@@ -226,6 +227,11 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value);
 int dad_debug_read_table(dad_model* m, int32_t which, int32_t t, float* host_out, int32_t capacity,
                          int32_t* width_out);
 int dad_debug_mish(const float* in, float* out, int64_t n, dad_stream_t stream);
+/* Which kernels a batch takes (host-side query, no device work): launches_out = conv launches of one
+ * denoiser evaluation through the small-batch consumer-combine kernels (csrc/conv_cc.hpp), 0 when the
+ * batch runs the batch-256 kernels; wide_out = how many of them are the streamed-weight form for
+ * wide layers (csrc/conv_ccw.hpp). */
+int dad_debug_small_batch_plan(dad_model* m, int32_t batch, int32_t* launches_out, int32_t* wide_out);
 
 #ifdef __cplusplus
 }

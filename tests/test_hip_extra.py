@@ -94,6 +94,48 @@ def test_wide_nets_at_a_ragged_multi_tile_batch(net, dev):
     assert max_abs(got, want) <= TOL_STEP
 
 
+@pytest.mark.parametrize("net,B", [("halfcheetah", 1), ("halfcheetah", 2), ("halfcheetah", 5), ("halfcheetah", 16),
+                                   ("door", 1), ("door", 3), ("door", 4), ("door", 16)])
+def test_wide_nets_small_batches_take_the_streamed_weight_kernels(net, B, dev):
+    """The `get_action` batch on the 1024 / 2048-channel nets: csrc/conv_ccw.hpp (weights streamed
+    global -> registers, K slices of whole 128 / 256-channel groups, 16- and 32-row tiles, stand-alone
+    1x1 residual convs consumed in pieces).  The plan must really be the consumer-combine one, one
+    forward and a short conditioned loop must match the oracle, and the batch-256 kernels must
+    agree with it to rounding."""
+    from dynamics_aware_diffusion_amd.utils import synth
+    diff = build(net, cases.NETS[net][4], "cosine", dev)
+    eng = diff._engine(dev)
+    assert eng.small_batch_plan(4)[1] >= 10 and eng.small_batch_plan(5) == (0, 0)     # default: up to 128 rows
+    eng.debug_set_option("ccw_max_rows", 512)           # (beyond: correct, just slower than the batch-256 kernels)
+    outs = []
+    try:
+        launches, wide = eng.small_batch_plan(B)
+        assert launches > 0 and wide >= 10, (launches, wide)
+        t = 123
+        x = torch.from_numpy(synth.normal_like(69, f"widecc.{net}.{B}", (B, 32, diff.transition_dim)))
+        want = _oracle_eps(net, x, t).numpy()
+        got = diff.model(x.to(dev), t).cpu().numpy()
+        assert max_abs(got, want) <= TOL_STEP
+        T = 3
+        noise = torch.from_numpy(synth.normal_like(70, f"widecc.noise.{net}.{B}", (T + 1, B, 32, diff.transition_dim)))
+        cond = torch.from_numpy(synth.uniform(70, f"widecc.cond.{net}", (1, diff.transition_dim), 0.9))
+        for cc in (1, 0):
+            eng.debug_set_option("cc", cc)
+            xl = noise[0].to(dev).clone()
+            xl[:, 0] = cond.to(dev)
+            eng.sample_loop(xl, T, noise_stack=noise[1:].to(dev).contiguous(), cond0=cond.to(dev))
+            torch.cuda.synchronize()
+            outs.append(xl.cpu().numpy())
+        assert eng.small_batch_plan(B)[0] == 0
+    finally:
+        eng.debug_set_option("cc", int(diff.model.small_batch_kernels))
+        eng.debug_set_option("ccw_max_rows", 128)
+    assert max_abs(outs[0], outs[1]) <= TOL_LOOP
+    if B <= 2:                                         # (the CPU oracle takes seconds per step here)
+        want_loop = orc.sample_loop(net_weights_torch(net), orc.schedule_buffers("cosine", cases.NETS[net][4]), noise, T, {0: cond})
+        assert max_abs(outs[0], want_loop.numpy()) <= TOL_LOOP
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 7, 17, 65])
 def test_ragged_batches_match_oracle(B, dev):
     from dynamics_aware_diffusion_amd.utils import synth
