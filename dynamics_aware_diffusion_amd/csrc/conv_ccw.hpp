@@ -44,9 +44,13 @@ __device__ __forceinline__ void ccw_issue(const CcSrc& s, CcwElem<RIDE>& e, int 
     const long off = (long)(r0 + r) * s.C + c;
     const long sstride = (long)s.rows * s.C;
     const int nsl = max(s.nsl, 1);
-    // unconditional, clamped: absent operands re-read something valid and are masked at the sum
+    // slabs that do not exist are neither loaded nor initialised (ccw_reduce skips them under the
+    // same wave-uniform condition).  These loads precede the weight ring, so the stricter waits a
+    // conditional load implies only cover loads of this same batch.
+    e.part[0] = ldg4(s.data + off);
 #pragma unroll
-    for (int k = 0; k < CC_MAX_SLABS; ++k) e.part[k] = ldg4(s.data + (long)min(k, nsl - 1) * sstride + off);
+    for (int k = 1; k < CC_MAX_SLABS; ++k)
+        if (k < nsl) e.part[k] = ldg4(s.data + (long)k * sstride + off);
     const float* some = s.bias != nullptr ? s.bias : s.data;
     e.b = ldg4((s.bias != nullptr ? s.bias : s.data) + (s.bias != nullptr ? c : 0));
     e.tv = ldg4(s.temb != nullptr ? s.temb + c : some);
@@ -54,9 +58,10 @@ __device__ __forceinline__ void ccw_issue(const CcSrc& s, CcwElem<RIDE>& e, int 
     if constexpr (RIDE) {
         const int nrs = max(s.nrs, 1);
         const bool hr = s.rslab != nullptr;              // (the other source of a concat may have none)
+        e.rp[0] = ldg4(hr ? s.rslab + off : some);
 #pragma unroll
-        for (int k = 0; k < CC_MAX_SLABS; ++k)
-            e.rp[k] = ldg4(hr ? s.rslab + (long)min(k, nrs - 1) * sstride + off : some);
+        for (int k = 1; k < CC_MAX_SLABS; ++k)
+            if (hr && k < nrs) e.rp[k] = ldg4(s.rslab + (long)k * sstride + off);
         e.rb = ldg4(hr ? s.rbias + c : some);
     } else {
         e.rp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -69,11 +74,8 @@ template <bool RIDE>
 __device__ __forceinline__ void ccw_reduce(const CcSrc& s, const CcwElem<RIDE>& e, float4& v, float4& ex) {
     float4 a = e.part[0];
 #pragma unroll
-    for (int k = 1; k < CC_MAX_SLABS; ++k) {
-        const float mk = k < s.nsl ? 1.0f : 0.0f;           // x * 1 + a is exact: same sums as a branch
-        a.x = fmaf(e.part[k].x, mk, a.x); a.y = fmaf(e.part[k].y, mk, a.y);
-        a.z = fmaf(e.part[k].z, mk, a.z); a.w = fmaf(e.part[k].w, mk, a.w);
-    }
+    for (int k = 1; k < CC_MAX_SLABS; ++k)
+        if (k < s.nsl) { a.x += e.part[k].x; a.y += e.part[k].y; a.z += e.part[k].z; a.w += e.part[k].w; }
     const float mb = s.bias != nullptr ? 1.0f : 0.0f;
     v.x = fmaf(e.b.x, mb, a.x); v.y = fmaf(e.b.y, mb, a.y); v.z = fmaf(e.b.z, mb, a.z); v.w = fmaf(e.b.w, mb, a.w);
     const float mt_ = s.temb != nullptr ? 1.0f : 0.0f, mr_ = s.res != nullptr ? 1.0f : 0.0f;
@@ -83,11 +85,8 @@ __device__ __forceinline__ void ccw_reduce(const CcSrc& s, const CcwElem<RIDE>& 
         md_ = s.rslab != nullptr ? 1.0f : 0.0f;
         r = e.rp[0];
 #pragma unroll
-        for (int k = 1; k < CC_MAX_SLABS; ++k) {
-            const float mk = k < s.nrs ? 1.0f : 0.0f;
-            r.x = fmaf(e.rp[k].x, mk, r.x); r.y = fmaf(e.rp[k].y, mk, r.y);
-            r.z = fmaf(e.rp[k].z, mk, r.z); r.w = fmaf(e.rp[k].w, mk, r.w);
-        }
+        for (int k = 1; k < CC_MAX_SLABS; ++k)
+            if (s.rslab != nullptr && k < s.nrs) { r.x += e.rp[k].x; r.y += e.rp[k].y; r.z += e.rp[k].z; r.w += e.rp[k].w; }
     }
     ex.x = e.tv.x * mt_ + e.rv.x * mr_ + (r.x + e.rb.x) * md_;
     ex.y = e.tv.y * mt_ + e.rv.y * mr_ + (r.y + e.rb.y) * md_;
@@ -175,6 +174,9 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
         x0 = ldg4(b);
         x1 = ldg4(b + (NR == 32 ? 8 : 16 * 16));       // second 8-channel group / second 16-row channel half
     };
+    // (unconditional: slots past the wave's last unit re-read it.  Loads under `if (i < nU)` make
+    // every later wait assume that none of them was issued — the first use of the input's loads
+    // then drains the whole ring)
     float4 wq0[CCW_DEPTH], wq1[CCW_DEPTH];
 #pragma unroll
     for (int i = 0; i < CCW_DEPTH; ++i) wload(i, wq0[i], wq1[i]);
