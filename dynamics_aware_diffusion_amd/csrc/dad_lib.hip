@@ -867,6 +867,8 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value) {
     else if (key == "cc") m->cc_enabled = value != 0;
     else if (key == "cc_max_rows") m->cc_max_rows = std::max(0, (int)value);
     else if (key == "ccw_max_rows") m->ccw_max_rows = std::max(0, (int)value);
+    else if (key == "ccw_min_blocks") m->ccw_min_blocks = std::max(1, (int)value);
+    else if (key == "ccw_prefer16") m->ccw_prefer16 = value != 0;
     else return fail(DAD_E_INVALID, "unknown option '%s'", name);
     return DAD_OK;
 }

@@ -135,6 +135,8 @@ struct HostModel {
     bool cc_enabled = true;                                    // small batches take the consumer-combine kernels
     int cc_max_rows = 512;                                     //   up to this many batch * horizon rows
     int ccw_max_rows = 128;                                    //   the same for nets whose plan needs conv_ccw.hpp (wide layers)
+    int ccw_min_blocks = 256;                                  //   blocks a wide layer keeps when its K slices are fattened
+    bool ccw_prefer16 = true;                                  //   two 16-row tiles instead of an LDS-short 32-row one
                                                                //   (measured crossover: batch 16 at H = 32)
     std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo
 };
@@ -810,7 +812,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
                 while ((cin + sl - 1) / sl > kCcwMaxSlabs) sl *= 2;
                 // fewer, fatter slices while the chip stays covered: every slab is re-read by all the M
                 // tiles of its consumer
-                while ((long)((cin + 2 * sl - 1) / (2 * sl)) * (op.M / 32) * nt >= 256 && 2 * sl <= cin && fits(2 * sl) &&
+                while ((long)((cin + 2 * sl - 1) / (2 * sl)) * (op.M / 32) * nt >= m.ccw_min_blocks && 2 * sl <= cin && fits(2 * sl) &&
                        (op.cin1 == 0 || op.cin0 % (2 * sl) == 0))
                     sl *= 2;
                 return fits(sl) ? sl : 0;
@@ -819,7 +821,12 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             if (op.Lout <= 16 && (batch + 16 / op.Lout - 1) / (16 / op.Lout) == (batch + 32 / op.Lout - 1) / (32 / op.Lout))
                 o.tile_rows = 16;
             slice = try_rows(o.tile_rows);
-            if (slice == 0 && o.tile_rows == 32 && op.Lout <= 16) { o.tile_rows = 16; slice = try_rows(16); }
+            if (o.tile_rows == 32 && op.Lout <= 16 && m.ccw_prefer16) {
+                // LDS-short 32-row tiles end up with twice the K slices (twice the slabs for the consumer
+                // to add); two 16-row tiles re-read the weights from L2 instead
+                const int s16 = try_rows(16);
+                if (slice == 0 || s16 >= 2 * slice) { o.tile_rows = 16; slice = s16; }
+            }
             if (slice == 0) return P;
             const int spt_w = o.tile_rows / op.Lout;
             int min_cpg = slice;

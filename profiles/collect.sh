@@ -41,9 +41,10 @@ run_pass pmc_sq 180 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_B
 run_pass x3_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/x3_trace_$stamp" -- "${bench[@]}" --precision f16x3
 run_pass x3_fetch 180 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/x3_fetch_$stamp" -- "${target[@]}" --precision f16x3
 run_pass x3_write 180 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/x3_write_$stamp" -- "${target[@]}" --precision f16x3
-# the T=1000 configurations (BASELINE configs 4 and 5) and the batch-1 planning call: kernel trace + HBM traffic
+# the T=1000 configurations (BASELINE configs 4 and 5) and the batch-1 planning calls (PointMaze and the two
+# wide nets): kernel trace + HBM traffic
 # of a 20-step loop each (per-launch averages do not need the thousand steps)
-for cfg in "halfcheetah 128" "door 128" "pointmaze 1"; do
+for cfg in "halfcheetah 128" "door 128" "pointmaze 1" "halfcheetah 1" "door 1"; do
   set -- $cfg
   run_pass "trace_$1_b$2" 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$1_b$2_$stamp" -- "${target[@]}" --arch "$1" --batch "$2" --denoise-steps 20
   run_pass "fetch_$1_b$2" 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch_$1_b$2_$stamp" -- "${target[@]}" --arch "$1" --batch "$2" --denoise-steps 20

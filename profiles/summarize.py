@@ -17,8 +17,19 @@ here = os.path.dirname(os.path.abspath(__file__))
 
 
 def one(pattern):
-    hits = glob.glob(os.path.join(src, pattern), recursive=True)
-    return max(hits, key=os.path.getmtime) if hits else None   # newest pass wins when runs were merged
+    """Newest file matching `<pass>_*/...`: the pass directory must be exactly <pass>_<HHMMSS>, so that
+    "trace_*" does not also match "trace_door_b1_*" (newest by the time stamp in the name: file
+    mtimes are those of the merge back from the GPU box)."""
+    import re
+    head = pattern.split("/")[0]
+    assert head.endswith("_*"), pattern
+    want = re.compile("^" + re.escape(head[:-2]) + r"_(\d{6})$")
+    hits = []
+    for f in glob.glob(os.path.join(src, pattern), recursive=True):
+        m = want.match(os.path.relpath(f, src).split(os.sep)[0])
+        if m:
+            hits.append((m.group(1), f))
+    return max(hits)[1] if hits else None
 
 
 stats = one("trace_*/**/*_kernel_stats.csv")
@@ -133,7 +144,8 @@ def pmc_all(dirname, counter):
 
 others = {}
 for arch, batch, workload in (("halfcheetah", 128, "halfcheetah_b128"), ("door", 128, "door_b128"),
-                              ("pointmaze", 1, "pointmaze_b1")):
+                              ("pointmaze", 1, "pointmaze_b1"), ("halfcheetah", 1, "halfcheetah_b1"),
+                              ("door", 1, "door_b1")):
     tag2 = f"{arch}_b{batch}"
     tr = one(f"trace_{tag2}_*/**/*_kernel_trace.csv")
     if not tr:
