@@ -912,6 +912,8 @@ int dad_debug_small_batch_plan(dad_model* m, int32_t batch, int32_t* launches_ou
             launches += o.launched;
             wide += o.launched && o.wide;
         }
+    static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;
+    if (trace && !cc.ok) fprintf(stderr, "[dad] batch %d: no small-batch plan (%s)\n", batch, cc.why.c_str());
     if (launches_out) *launches_out = launches;
     if (wide_out) *wide_out = wide;
     return DAD_OK;

@@ -730,7 +730,9 @@ struct CcPlan {
     std::vector<CcOp> ops;
     long slab_floats = 0;
     int final_producer = -1;
+    std::string why;         // when !ok: which rule refused the plan (diagnostic)
 };
+inline CcPlan& refuse(CcPlan& P, const char* why) { P.why = why; return P; }
 
 inline CcPlan cc_plan(const HostModel& m, int batch) {
     CcPlan P;
@@ -738,9 +740,9 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     const std::vector<ConvOp>& convs = m.plan.convs;
     if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 32 ||
         (long)batch * c.horizon > m.cc_max_rows)
-        return P;
+        return refuse(P, "disabled, split-f16 arithmetic, horizon > 32 or more than cc_max_rows rows");
     for (const ConvOp& op : convs)      // weight images in 16-channel granules only
-        if ((op.kc != 16 && !op.bdir) || op.cat0 >= 0 || op.x3 || (!op.rname.empty() && !op.ride)) return P;
+        if ((op.kc != 16 && !op.bdir) || op.cat0 >= 0 || op.x3 || (!op.rname.empty() && !op.ride)) return refuse(P, "a weight image not in 16-channel granules, or an identity residual over a concat");
     P.ops.resize(convs.size());
     std::vector<int> owner(m.plan.bufs.size(), -1);     // buffer -> conv whose output it holds
     std::vector<char> materialised(convs.size(), 0);
@@ -761,8 +763,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             in.kind = 3; in.producer = q; materialised[q] = 1;
             return true;
         };
-        if (!input(op.src0, o.in0) || !input(op.src1, o.in1)) return P;
-        if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return P;
+        if (!input(op.src0, o.in0) || !input(op.src1, o.in1)) return refuse(P, "input with no known producer");
+        if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return refuse(P, "output columns not a multiple of 32, or a length that does not divide 32");
         // K slices: whole GroupNorm groups of the tensor being finished
         const int cin = op.cin0 + op.cin1;
         int need = 32, max_slabs_in = 0;
@@ -776,7 +778,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
                 if (!q.norm.empty()) {
                     need = std::max(need, q.cout / 8);
                     max_pair = std::max(max_pair, (long)(q.cout / 8) * op.Lin);
-                    if (need % (q.cout / 8) != 0) return P;          // slices must hold whole groups
+                    if (need % (q.cout / 8) != 0) return refuse(P, "inputs whose GroupNorm widths do not nest");          // slices must hold whole groups
                 }
             }
         int slice = need;
@@ -786,7 +788,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         // anything wider goes to conv_ccw (weights streamed global -> registers)
         o.wide = slice > kCcMaxSlice || max_pair > 1024 || op.bdir || op.kind == CONV_1X1;   // (conv_cc has no 1x1 form)
         if (!o.wide) {
-            if (slice % 32 != 0) return P;
+            if (slice % 32 != 0) return refuse(P, "K slice not a multiple of 32 channels");
             // 16-row tiles (16x16x4 MFMAs, half the padded rows) as long as the layer still fits one wave
             // of blocks; beyond that the extra N tiles only re-stream the weights
             o.tile_rows = 32;
@@ -798,7 +800,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         } else {
             if (op.src0 == -2 || (op.cin0 & 3) || (op.cin1 & 3) || max_slabs_in > kCcwMaxSlabs ||
                 max_pair > kCcwMaxPair)
-                return P;
+                return refuse(P, "wide layer: ragged channels, more than 8 slabs to add, or a GroupNorm pair above 2048 elements");
             // tile rows: 16 when that needs no more N tiles than 32 would (batch 1 / 2 on short levels),
             // or when a 32-row tile of the narrowest admissible slice does not fit LDS
             auto try_rows = [&](int rows) -> int {
@@ -827,21 +829,21 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
                 const int s16 = try_rows(16);
                 if (slice == 0 || s16 >= 2 * slice) { o.tile_rows = 16; slice = s16; }
             }
-            if (slice == 0) return P;
+            if (slice == 0) return refuse(P, "wide layer: no K slice of at most 8 slabs fits LDS");
             const int spt_w = o.tile_rows / op.Lout;
             int min_cpg = slice;
             for (const CcInput* in : {&o.in0, &o.in1})
                 if (in->kind == 3 && !convs[in->producer].norm.empty())
                     min_cpg = std::min(min_cpg, convs[in->producer].cout / 8);
-            if ((long)spt_w * (slice / min_cpg) > kCcwMaxPairs) return P;
+            if ((long)spt_w * (slice / min_cpg) > kCcwMaxPairs) return refuse(P, "wide layer: more than 64 (sample, group) pairs per block");
         }
-        if (op.cin1 > 0 && op.cin0 % slice != 0) return P;     // a slice may not straddle the concat
+        if (op.cin1 > 0 && op.cin0 % slice != 0) return refuse(P, "a K slice would straddle the concat");     // a slice may not straddle the concat
         o.slice_ch = slice;
         o.kslices = (cin + slice - 1) / slice;
-        if ((long)o.kslices * slice > op.cin_pad) return P;    // weight image too short for whole slices
+        if ((long)o.kslices * slice > op.cin_pad) return refuse(P, "weight image too short for whole K slices");    // weight image too short for whole slices
         // a (sample, group) pair of the output is normalised by its consumer: conv_cc / final_cc take at
         // most 1024 elements per pair, conv_ccw 2048 (checked again where the consumer is planned)
-        if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > kCcwMaxPair) return P;
+        if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > kCcwMaxPair) return refuse(P, "GroupNorm pair above 2048 elements");
         const int spt = o.tile_rows / op.Lout;
         o.ntiles = (batch + spt - 1) / spt;
         o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;
@@ -858,7 +860,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             const size_t e = (size_t)2 * 8 * o.tile_rows * 36;
             o.lds_bytes = std::max(k, e) * sizeof(float);
         }
-        if (o.lds_bytes > dad::kLdsBytes) return P;
+        if (o.lds_bytes > dad::kLdsBytes) return refuse(P, "a launch does not fit LDS");
         // how the output gets finished
         if (op.res == -2) o.res_kind = 1;
         else if (op.res >= 0) {
@@ -867,20 +869,20 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             else if (q >= 0 && materialised[q]) { o.res_kind = 2; o.res_buf = op.res; }
             else if (q >= 0 && convs[q].kind == CONV_1X1 && convs[q].norm.empty() && P.ops[q].launched) {
                 o.res_kind = 4; o.res_ride = q;          // the block's own 1x1 residual conv, still in pieces
-            } else return P;                             // residual not finished yet: not a plan we know
+            } else return refuse(P, "residual tensor neither finished nor a 1x1 conv in pieces");                             // residual not finished yet: not a plan we know
         }
         owner[op.dst] = (int)i;
     }
     P.final_producer = owner[m.plan.final_act];
-    if (P.final_producer < 0 || materialised[P.final_producer]) return P;
+    if (P.final_producer < 0 || materialised[P.final_producer]) return refuse(P, "final conv input already finished");
     // the streamed-weight form re-reads the weights once per N tile: measured against the batch-256
     // kernels it pays up to 4 plans of 32 positions (HalfCheetah 410 / 627 us per step at batch 1 / 4
     // against 597 / 653; 973 against 683 at batch 6)
     for (const CcOp& o : P.ops)
-        if (o.launched && o.wide && (long)batch * c.horizon > m.ccw_max_rows) return P;
+        if (o.launched && o.wide && (long)batch * c.horizon > m.ccw_max_rows) return refuse(P, "wide layers and more than ccw_max_rows rows");
     {   // final_cc_kernel normalises a pair in one wave's registers
         const ConvOp& f = convs[P.final_producer];
-        if ((long)(f.cout / 8) * f.Lout > 1024 || P.ops[P.final_producer].kslices > kCcMaxSlabs) return P;
+        if ((long)(f.cout / 8) * f.Lout > 1024 || P.ops[P.final_producer].kslices > kCcMaxSlabs) return refuse(P, "final conv: GroupNorm pair above 1024 elements");
     }
     P.slab_floats = off;
     P.ok = true;
