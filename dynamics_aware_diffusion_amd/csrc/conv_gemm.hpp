@@ -748,8 +748,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             }
             const float4 rb = ldg4(p.rbias + m0 + ecol[k]);
             if (eoff[k] >= 0)
-                *reinterpret_cast<float4*>(p.rdst + eoff[k]) =
-                    make_float4(v.x + rb.x, v.y + rb.y, v.z + rb.z, v.w + rb.w);
+                store_f4_sc1(p.rdst + eoff[k], make_float4(v.x + rb.x, v.y + rb.y, v.z + rb.z, v.w + rb.w));
         }
     }
 
@@ -854,9 +853,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     for (int k = 0; k < F4PL; ++k) {
         if (eoff[k] < 0) continue;
         // tmask, rmask in {0, 1}: fma(temb, 1, res * 1) is temb + res with one rounding, as before
-        *reinterpret_cast<float4*>(p.dst + eoff[k]) =
+        const float4 o4 =
             make_float4(y[k][0] + fmaf(temb4[k].x, tmask, res4[k].x * rmask), y[k][1] + fmaf(temb4[k].y, tmask, res4[k].y * rmask),
                         y[k][2] + fmaf(temb4[k].z, tmask, res4[k].z * rmask), y[k][3] + fmaf(temb4[k].w, tmask, res4[k].w * rmask));
+        // write-through: nothing of the tile is left dirty in this XCD's L2 for the end-of-kernel
+        // release to write back (+0.5 % at batch 256, +0.7 % on Door; same bytes)
+        store_f4_sc1(p.dst + eoff[k], o4);
     }
     DAD_STAMP(5);
 }
