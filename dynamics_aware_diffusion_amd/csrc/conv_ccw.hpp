@@ -261,6 +261,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
             if (lane == 0) { STb[2 * pr] = mean; STb[2 * pr + 1] = rstd; }
         }
         __syncthreads();
+        CC_STAMP(7);
         for (int i = tid; i < n4; i += CC_THREADS) {
             const int r = i / q4, q = i - r * q4;
             const int smp = r >> lshL, l = r & (Lin - 1);
