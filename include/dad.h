@@ -208,7 +208,9 @@ int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, doub
  * order), "split_target" (blocks a split-K layer aims for), "cc" (small batches take the
  * consumer-combine kernels of csrc/conv_cc.hpp; 0 = always the batch-256 kernels), "cc_max_rows"
  * (largest batch * horizon that does), "ccw_max_rows" (the same bound for nets whose small-batch plan
- * needs the streamed-weight kernels of csrc/conv_ccw.hpp: GroupNorm groups wider than 64 channels).
+ * needs the streamed-weight kernels of csrc/conv_ccw.hpp: GroupNorm groups wider than 64 channels),
+ * "ccw_min_blocks" (blocks a wide layer keeps when its K slices are fattened), "ccw_prefer16" (two
+ * 16-row tiles instead of a 32-row tile whose K slice LDS would halve).
  * Results do not depend on these choices beyond fp32 summation order. */
 int dad_debug_set_tile(dad_model* m, int32_t cfg);
 int dad_debug_set_option(dad_model* m, const char* name, int32_t value);
