@@ -97,7 +97,7 @@ __device__ __forceinline__ void ccw_reduce(const CcSrc& s, const CcwElem<RIDE>& 
 // grid = (K slices, M / 32, N tiles of NR rows), 8 waves.  Host contract (cc_plan): weight image in
 // 16-channel granules, slice a multiple of 32 and of the finished tensor's group width, at most
 // CC_MAX_SLABS partial slabs per input, channel counts multiples of 4, pairs of a block <= CCW_MAX_PAIRS
-// with at most 2048 elements each.
+// with at most 8192 elements each (up to 2048 stay in registers between the two passes).
 template <int TAPS, int STRIDE, bool RES, bool RIDE, int NR>
 __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
     static_assert(NR == 16 || NR == 32, "tile rows");
@@ -237,6 +237,28 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
         const float inv_cnt = 1.0f / (float)(Lin * cpg);
         for (int pr = wave; pr < nvalid * groups; pr += CC_THREADS / 64) {
             const int smp = pr / groups, g = pr - smp * groups;
+            if (cnt4 > 8 * 64) {
+                // pairs beyond 2048 elements (e.g. 2048 channels at 16 positions): same two passes,
+                // re-reading LDS instead of keeping the pair in registers
+                const float* base = Xb + (smp * SEG + PAD) * XS + g * cpg;
+                float sum = 0.0f;
+                for (int j = lane; j < cnt4; j += 64) {
+                    const int l = j / cqp, cl = (j - l * cqp) * 4;
+                    const float4 t = *reinterpret_cast<const float4*>(base + l * XS + cl);
+                    sum += (t.x + t.y) + (t.z + t.w);
+                }
+                const float mean = wave_sum(sum) * inv_cnt;
+                float sq = 0.0f;
+                for (int j = lane; j < cnt4; j += 64) {
+                    const int l = j / cqp, cl = (j - l * cqp) * 4;
+                    const float4 t = *reinterpret_cast<const float4*>(base + l * XS + cl);
+                    const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+                    sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_cnt + 1e-5f);
+                if (lane == 0) { STb[2 * pr] = mean; STb[2 * pr + 1] = rstd; }
+                continue;
+            }
             float4 vv[8];
             float sum = 0.0f;
 #pragma unroll

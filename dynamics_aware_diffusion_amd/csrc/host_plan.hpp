@@ -705,7 +705,7 @@ constexpr int kCcMaxSlice = 64;          // channels per K slice of conv_cc: wei
                                          // inside LDS and 6 float4 of weights per thread
 constexpr int kCcwMaxSlabs = 8;          // conv_ccw (wide layers): slabs per input, one round trip
 using dad::kCcwMaxPairs;
-constexpr int kCcwMaxPair = 2048;        // elements of one pair (8 float4 per lane)
+constexpr int kCcwMaxPair = 8192;        // elements of one pair (up to 2048 stay in registers between the passes)
 struct CcInput {
     int kind = 0;            // 0 none, 1 external trajectory, 2 finished tensor in a plan buffer, 3 in pieces
     int buf = -1;            // kind 2 / 3: the tensor's activation buffer (kind 3: where it is materialised)
@@ -800,7 +800,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         } else {
             if (op.src0 == -2 || (op.cin0 & 3) || (op.cin1 & 3) || max_slabs_in > kCcwMaxSlabs ||
                 max_pair > kCcwMaxPair)
-                return refuse(P, "wide layer: ragged channels, more than 8 slabs to add, or a GroupNorm pair above 2048 elements");
+                return refuse(P, "wide layer: ragged channels, more than 8 slabs to add, or a GroupNorm pair above 8192 elements");
             // tile rows: 16 when that needs no more N tiles than 32 would (batch 1 / 2 on short levels),
             // or when a 32-row tile of the narrowest admissible slice does not fit LDS
             auto try_rows = [&](int rows) -> int {
@@ -842,8 +842,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         o.kslices = (cin + slice - 1) / slice;
         if ((long)o.kslices * slice > op.cin_pad) return refuse(P, "weight image too short for whole K slices");    // weight image too short for whole slices
         // a (sample, group) pair of the output is normalised by its consumer: conv_cc / final_cc take at
-        // most 1024 elements per pair, conv_ccw 2048 (checked again where the consumer is planned)
-        if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > kCcwMaxPair) return refuse(P, "GroupNorm pair above 2048 elements");
+        // most 1024 elements per pair, conv_ccw 8192 (checked again where the consumer is planned)
+        if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > kCcwMaxPair) return refuse(P, "GroupNorm pair above 8192 elements");
         const int spt = o.tile_rows / op.Lout;
         o.ntiles = (batch + spt - 1) / spt;
         o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;

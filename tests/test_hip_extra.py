@@ -414,6 +414,8 @@ def test_graph_replay_with_inkernel_noise(dev):
     (5, 32, (1, 4, 2, 1), 32, 2),      # two such stages
     (32, 32, (1, 2), 32, 3),           # transition_dim == dim: the first block's residual is the
                                        # trajectory itself (nn.Identity, temporal_unet.py:92-94)
+    (9, 256, (1, 8), 32, 2),           # 2048 channels at 16 positions: GroupNorm pairs of 4096 elements
+                                       # (conv_ccw re-reads LDS between the passes at small batch)
 ], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}")
 def test_assorted_architectures_match_oracle(arch, dev):
     """Shapes outside the three BASELINE architectures, against the oracle on seeded inputs."""
