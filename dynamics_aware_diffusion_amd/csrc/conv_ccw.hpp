@@ -25,6 +25,14 @@ namespace dad {
 constexpr int CCW_DEPTH = 8;          // (granule, tap) units of weights in flight per wave: 16 float4 per lane
 constexpr int CCW_MAX_PAIRS = kCcwMaxPairs;
 
+// x / d for a wave-uniform d that is a power of two in every net this path was built for (channel counts
+// of 128 .. 2048): a shift then, the ~25-instruction integer division otherwise (one uniform branch).
+struct CcwDiv {
+    int d, sh;
+    __device__ __forceinline__ explicit CcwDiv(int d_) : d(d_), sh((d_ & (d_ - 1)) == 0 ? 31 - __clz(d_) : -1) {}
+    __device__ __forceinline__ int operator()(int x) const { return sh >= 0 ? x >> sh : x / d; }
+};
+
 // Loads of one float4 of the input slice, issued together and summed later (registers only).
 template <bool RIDE>
 struct CcwElem {
@@ -36,10 +44,11 @@ struct CcwElem {
 
 // element i of the slice: row r = i / q4 of the tile, channel quad q = i % q4
 template <bool RIDE>
-__device__ __forceinline__ void ccw_issue(const CcSrc& s, CcwElem<RIDE>& e, int i, int n4, int q4, int r0,
-                                          int nrows_valid, int c0) {
+__device__ __forceinline__ void ccw_issue(const CcSrc& s, CcwElem<RIDE>& e, int i, int n4, int q4, const CcwDiv& by_q4,
+                                          int r0, int nrows_valid, int c0) {
     const int ii = min(i, n4 - 1);
-    const int r = min(ii / q4, nrows_valid - 1), q = ii - (ii / q4) * q4;
+    const int rr = by_q4(ii);
+    const int r = min(rr, nrows_valid - 1), q = ii - rr * q4;
     const int c = c0 + 4 * q;
     const long off = (long)(r0 + r) * s.C + c;
     const long sstride = (long)s.rows * s.C;
@@ -144,12 +153,13 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
     const int q4 = nch >> 2;
     const int rows_tile = SPT * Lin, rows_valid = nvalid * Lin, r0 = s0 * Lin;
     const int n4 = rows_valid * q4;                    // float4 elements to finish
+    const CcwDiv by_q4(q4);
     const bool gn = src.gamma != nullptr;
     const bool publish = mt == 0 && src.nsl > 0 && src.mat != nullptr;
 
     // ---- 1. the first element of every thread: loads issued before anything else ---------------
     CcwElem<RIDE> e0;
-    ccw_issue<RIDE>(src, e0, tid, n4, q4, r0, rows_valid, cs0);
+    ccw_issue<RIDE>(src, e0, tid, n4, q4, by_q4, r0, rows_valid, cs0);
     float4 gam0 = make_float4(0.f, 0.f, 0.f, 0.f), bet0 = gam0;
     {
         const int cq = min(tid, q4 - 1) * 4;
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
         if (i >= n4) return;
         float4 v, ex;
         ccw_reduce<RIDE>(src, e, v, ex);
-        const int r = i / q4, q = i - r * q4;
+        const int r = by_q4(i), q = i - r * q4;
         const int smp = r >> lshL, l = r & (Lin - 1);
         float* xp = Xb + (smp * SEG + PAD + l) * XS + 4 * q;
         if (gn) {
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
     finish_first_pass(tid, e0);
     for (int i = tid + CC_THREADS; i < n4; i += CC_THREADS) {          // further elements: second round trip
         CcwElem<RIDE> e;
-        ccw_issue<RIDE>(src, e, i, n4, q4, r0, rows_valid, cs0);
+        ccw_issue<RIDE>(src, e, i, n4, q4, by_q4, r0, rows_valid, cs0);
         finish_first_pass(i, e);
     }
     if (gn && q4 > CC_THREADS)
@@ -233,6 +243,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
     if (gn) {
         // statistics of every (sample, group) pair of the slice: one wave per pair, from LDS
         const int cpg = src.cpg, groups = nch / cpg, cqp = cpg >> 2;
+        const CcwDiv by_cqp(cqp);
         const int cnt4 = Lin * cqp;
         const float inv_cnt = 1.0f / (float)(Lin * cpg);
         for (int pr = wave; pr < nvalid * groups; pr += CC_THREADS / 64) {
@@ -243,14 +254,14 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
                 const float* base = Xb + (smp * SEG + PAD) * XS + g * cpg;
                 float sum = 0.0f;
                 for (int j = lane; j < cnt4; j += 64) {
-                    const int l = j / cqp, cl = (j - l * cqp) * 4;
+                    const int l = by_cqp(j), cl = (j - l * cqp) * 4;
                     const float4 t = *reinterpret_cast<const float4*>(base + l * XS + cl);
                     sum += (t.x + t.y) + (t.z + t.w);
                 }
                 const float mean = wave_sum(sum) * inv_cnt;
                 float sq = 0.0f;
                 for (int j = lane; j < cnt4; j += 64) {
-                    const int l = j / cqp, cl = (j - l * cqp) * 4;
+                    const int l = by_cqp(j), cl = (j - l * cqp) * 4;
                     const float4 t = *reinterpret_cast<const float4*>(base + l * XS + cl);
                     const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
                     sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
                 const int j = lane + 64 * k;
                 const bool on = j < cnt4;
                 const int jj = on ? j : 0;
-                const int l = jj / cqp, cl = (jj - l * cqp) * 4;
+                const int l = by_cqp(jj), cl = (jj - l * cqp) * 4;
                 const float4 t = *reinterpret_cast<const float4*>(Xb + (smp * SEG + PAD + l) * XS + g * cpg + cl);
                 vv[k] = on ? t : make_float4(0.f, 0.f, 0.f, 0.f);
                 sum += (vv[k].x + vv[k].y) + (vv[k].z + vv[k].w);
@@ -285,9 +296,9 @@ __global__ __launch_bounds__(CC_THREADS) void conv_ccw(const CcParams p) {
         __syncthreads();
         CC_STAMP(7);
         for (int i = tid; i < n4; i += CC_THREADS) {
-            const int r = i / q4, q = i - r * q4;
+            const int r = by_q4(i), q = i - r * q4;
             const int smp = r >> lshL, l = r & (Lin - 1);
-            const int pr = smp * groups + (4 * q) / cpg;
+            const int pr = smp * groups + by_cqp(q);
             const float mean = STb[2 * pr], rstd = STb[2 * pr + 1];
             float* xp = Xb + (smp * SEG + PAD + l) * XS + 4 * q;
             const float4 v = *reinterpret_cast<const float4*>(xp);
