@@ -8,6 +8,8 @@ path and compares it with the CPU oracle at the forward tolerance of the parity 
 and a short conditioned sampling loop with injected noise (2e-5).
 Round 1: seeds 1, 7, 11, 12, 13 (forward) and 21, 22 (forward + loop) x 40 cases, 0 failures,
 0 refusals (the first sweep found the identity-residual-over-concat decoder block, since supported).
+Round 2: seeds 31 / 52 `small` (130 + 65 cases), 41 / 43 `wide` (56 + 99 cases, 142 of them through
+conv_ccw), 51 default (58 cases): 0 failures, 0 refusals.
 `wide`: the same on nets of 1024+ channels at batches of up to 128 rows (conv_ccw).
 `small`: batches 1..16 in fp32 only, i.e. the consumer-combine kernels (conv_cc / conv_ccw); the line
 shows how many launches of the case took them and how many the streamed-weight form."""
