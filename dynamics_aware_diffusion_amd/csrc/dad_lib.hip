@@ -472,15 +472,17 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         HIP_TRY(hipGetLastError());
         return DAD_OK;
     }
-    const size_t lds = dad::final_lds_floats(c.transition_dim, c.dim) * sizeof(float);
-    if (lds > dad::kLdsBytes)
-        return fail(DAD_E_INVALID, "final 1x1 conv does not fit LDS (td=%d, dim=%d)", c.transition_dim, c.dim);
     const long N = (long)batch * c.horizon;
     // columns of the transition are spread over gridDim.y when the row tiles alone leave CUs idle
+    // (a block stages only the weight rows of its own columns), and further until a block fits LDS
     const long row_tiles = (N + dad::FINAL_COLS - 1) / dad::FINAL_COLS;
     const int jg = 256 / dad::FINAL_COLS;
     const long col_groups = (c.transition_dim + jg - 1) / jg;
-    const long gy = std::max(1L, std::min(col_groups, 512 / row_tiles));
+    long gy = std::max(1L, std::min(col_groups, 512 / row_tiles));
+    while (gy < col_groups && dad::final_lds_floats(c.transition_dim, c.dim, (int)gy) * sizeof(float) > dad::kLdsBytes) ++gy;
+    const size_t lds = dad::final_lds_floats(c.transition_dim, c.dim, (int)gy) * sizeof(float);
+    if (lds > dad::kLdsBytes)
+        return fail(DAD_E_INVALID, "final 1x1 conv does not fit LDS (td=%d, dim=%d)", c.transition_dim, c.dim);
     hipLaunchKernelGGL(dad::final_posterior_kernel, dim3((unsigned)row_tiles, (unsigned)gy), dim3(256), lds, st, p);
     HIP_TRY(hipGetLastError());
     return DAD_OK;

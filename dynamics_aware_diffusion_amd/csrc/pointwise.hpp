@@ -92,8 +92,39 @@ struct FinalParams {
 };
 
 constexpr int FINAL_COLS = 32;   // trajectory positions per block (256 blocks at B*H = 8192)
-__host__ __device__ inline size_t final_lds_floats(int td, int dim) {
-    return (size_t)td * dim + ((td + 3) & ~3) + (size_t)FINAL_COLS * (dim + 4);
+// a block keeps the weight rows of ITS output columns (gy = gridDim.y column groups), the biases and
+// the activation tile
+__host__ __device__ inline int final_rows_local(int td, int gy) {
+    constexpr int JG = 256 / FINAL_COLS;
+    const int col_groups = (td + JG - 1) / JG;
+    return (col_groups + gy - 1) / gy * JG;
+}
+__host__ __device__ inline size_t final_lds_floats(int td, int dim, int gy) {
+    return (size_t)final_rows_local(td, gy) * dim + ((td + 3) & ~3) + (size_t)FINAL_COLS * (dim + 4);
+}
+
+// K output columns j0, j0 + jstep, ... of one position: dot products of the activation row with K
+// weight rows (local rows of the block, JG apart), every read of the activation row shared.
+template <int K>
+__device__ __forceinline__ void final_dots(const float* wrow0, const float* arow, int dim, int rstep, float* acc) {
+    const float* wr[K];
+    float a[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        wr[k] = wrow0 + (long)k * rstep;                 // the thread's next column: JG local rows further
+        a[k][0] = a[k][1] = a[k][2] = a[k][3] = 0.0f;
+    }
+    for (int c = 0; c < dim; c += 4) {
+        const float4 av = *reinterpret_cast<const float4*>(arow + c);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr[k] + c);
+            a[k][0] = fmaf(wv.x, av.x, a[k][0]); a[k][1] = fmaf(wv.y, av.y, a[k][1]);
+            a[k][2] = fmaf(wv.z, av.z, a[k][2]); a[k][3] = fmaf(wv.w, av.w, a[k][3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = (a[k][0] + a[k][1]) + (a[k][2] + a[k][3]);     // four chains, summed pairwise
 }
 
 // One block = 32 (b, l) positions.  The [32][dim] activation slab and the [td][dim] weights
@@ -104,8 +135,10 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
     extern __shared__ __attribute__((aligned(16))) float ws[];
     const int td = p.td, dim = p.dim;
     const int rs = dim + 4;                // tile row stride
-    float* wl = ws;                        // [td][dim]
-    float* bl = wl + td * dim;             // [td] (+ pad to 4)
+    constexpr int JG = 256 / FINAL_COLS;
+    const int rows_local = final_rows_local(td, (int)gridDim.y);
+    float* wl = ws;                        // [rows_local][dim]: column j of this block at row (j / (JG * gy)) * JG + j % JG
+    float* bl = wl + rows_local * dim;     // [td] (+ pad to 4)
     float* tile = bl + ((td + 3) & ~3);    // [32][dim+4]
     const long N = (long)p.B * p.H;
     const long n0 = (long)blockIdx.x * FINAL_COLS;
@@ -118,11 +151,12 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
     }
     // blockIdx.y owns the output columns j with (j / JG) % gridDim.y == blockIdx.y: wide transitions
     // (and short grids) spread their columns over more blocks; each block stages only its own rows
-    constexpr int JG = 256 / FINAL_COLS;
-    for (int i = threadIdx.x; i < td * dq; i += blockDim.x) {
-        const int j = i / dq;
-        if ((j / JG) % (int)gridDim.y == (int)blockIdx.y)
-            *reinterpret_cast<float4*>(wl + i * 4) = *reinterpret_cast<const float4*>(p.w + i * 4);
+    for (int i = threadIdx.x; i < rows_local * dq; i += blockDim.x) {
+        const int lr = i / dq, q = i - lr * dq;
+        const int j = ((lr / JG) * (int)gridDim.y + (int)blockIdx.y) * JG + lr % JG;     // global column of local row lr
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < td) v = *reinterpret_cast<const float4*>(p.w + (long)j * dim + q * 4);
+        *reinterpret_cast<float4*>(wl + i * 4) = v;
     }
     for (int i = threadIdx.x; i < td; i += blockDim.x) bl[i] = p.bias[i];
     __syncthreads();
@@ -134,27 +168,18 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
     const int b = (int)(n / p.H);
     const int l = (int)(n - (long)b * p.H);
     const float* arow = tile + col * rs;
-    for (int j = (int)blockIdx.y * JG + jg; j < td; j += JG * (int)gridDim.y) {
-        const float* wr = wl + j * dim;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;       // four chains, summed pairwise
-        for (int c = 0; c < dim; c += 4) {
-            const float4 wv = *reinterpret_cast<const float4*>(wr + c);
-            const float4 av = *reinterpret_cast<const float4*>(arow + c);
-            a0 = fmaf(wv.x, av.x, a0); a1 = fmaf(wv.y, av.y, a1);
-            a2 = fmaf(wv.z, av.z, a2); a3 = fmaf(wv.w, av.w, a3);
-        }
-        const float acc = (a0 + a1) + (a2 + a3);
+    // posterior update of one output (diffusion.py:159-223, policies.py:84-110)
+    auto finish = [&](int j, float acc, float xv) {
         const long idx = n * td + j;
         const float out = acc + bl[j];
         if (p.eps_out != nullptr) p.eps_out[idx] = out;
-        if (p.x_out_disabled && p.mean_out == nullptr) continue;
-        const float xv = p.x[idx];
+        if (p.x_out_disabled && p.mean_out == nullptr) return;
         float x0 = p.predict_epsilon ? p.c_recip * xv - p.c_recipm1 * out : out;
         if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         float mean = p.coef1 * x0 + p.coef2 * xv;
         if (p.guide != nullptr) mean = mean + p.guide_scale * p.guide[idx];
         if (p.mean_out != nullptr) p.mean_out[idx] = mean;
-        if (p.x_out_disabled) continue;
+        if (p.x_out_disabled) return;
         const float z = (p.noise != nullptr)
                             ? p.noise[idx]
                             : philox_normal(p.elem_offset + (uint64_t)idx, p.draw,
@@ -162,6 +187,30 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
         float xn = mean + p.sigma * z;
         if (l == 0 && p.cond0 != nullptr) xn = p.cond0[(p.cond_per_row ? (long)b * td : 0) + j];
         p.x[idx] = xn;
+    };
+    // up to JB of the thread's columns share every read of its activation row (the weight rows are
+    // wave-wide broadcasts: the activation row is the LDS traffic); per output the same four chains.
+    // The block-uniform count of live columns picks the instantiation (PointMaze: one).
+    constexpr int JB = 4;
+    const int jstep = JG * (int)gridDim.y;
+    for (int jb = (int)blockIdx.y * JG; jb < td; jb += JB * jstep) {
+        const int j0 = jb + jg;
+        const int live = min(JB, (td - 1 - jb) / jstep + 1);      // columns jb + k * jstep < td
+        float acc[JB], xv[JB];
+        // x_t of the thread's outputs: loaded ahead of the dot products (each element of x is read and
+        // written by exactly one thread of the grid)
+#pragma unroll
+        for (int k = 0; k < JB; ++k) xv[k] = p.x[n * td + min(j0 + k * jstep, td - 1)];
+        const float* wrow0 = wl + (long)(((jb / JG) / (int)gridDim.y) * JG + jg) * dim;   // local row of column j0
+        switch (live) {
+            case 1: final_dots<1>(wrow0, arow, dim, JG * dim, acc); break;
+            case 2: final_dots<2>(wrow0, arow, dim, JG * dim, acc); break;
+            case 3: final_dots<3>(wrow0, arow, dim, JG * dim, acc); break;
+            default: final_dots<4>(wrow0, arow, dim, JG * dim, acc); break;
+        }
+#pragma unroll
+        for (int k = 0; k < JB; ++k)
+            if (k < live && j0 + k * jstep < td) finish(j0 + k * jstep, acc[k], xv[k]);
     }
 }
 
