@@ -595,6 +595,8 @@ __global__ __launch_bounds__(CC_THREADS) void final_cc_kernel(const FinalCcParam
         const int jj = o / H, l = o - jj * H, j = jlo + jj;
         const float* wr = wl + jj * dim;
         const float* arow = tile + l * rs;
+        const long idx = ((long)b * H + l) * td + j;
+        const float xv = p.x[idx];                               // ahead of the dot product: its latency hides there
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;       // four chains, summed pairwise
         for (int c = 0; c < dim; c += 4) {
             const float4 wv = *reinterpret_cast<const float4*>(wr + c);
@@ -603,10 +605,8 @@ __global__ __launch_bounds__(CC_THREADS) void final_cc_kernel(const FinalCcParam
             a2 = fmaf(wv.z, av.z, a2); a3 = fmaf(wv.w, av.w, a3);
         }
         const float out = ((a0 + a1) + (a2 + a3)) + bl[j];
-        const long idx = ((long)b * H + l) * td + j;
         if (p.eps_out != nullptr) p.eps_out[idx] = out;
         if (p.x_out_disabled && p.mean_out == nullptr) continue;
-        const float xv = p.x[idx];
         float x0 = p.predict_epsilon ? p.c_recip * xv - p.c_recipm1 * out : out;
         if (p.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         float mean = p.coef1 * x0 + p.coef2 * xv;
