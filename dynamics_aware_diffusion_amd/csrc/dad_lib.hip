@@ -872,6 +872,13 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value) {
     else if (key == "ccw_min_blocks") m->ccw_min_blocks = std::max(1, (int)value);
     else if (key == "ccw_prefer16") m->ccw_prefer16 = value != 0;
     else return fail(DAD_E_INVALID, "unknown option '%s'", name);
+    // every option changes which launches a captured loop holds, and not all of them are part of the
+    // graph key: drop the cache (a replay may still be in flight: wait for the device first)
+    if (!m->graphs.empty()) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+        m->graphs.clear();
+    }
     return DAD_OK;
 }
 
