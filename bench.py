@@ -261,14 +261,22 @@ def main() -> None:
         conv_ms, launches, conv_flops = eng.profile_read()
         eng.profile_enable(False)
         diff_.use_graph, diff_.n_timesteps = graph, steps_keep
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        # The event-bracketed pass runs a few per cent slower than the timed loop (eager launches, event
+        # records between denoiser evaluations), and a kernel cannot take longer than the step that
+        # contains it: the conv time per denoise step is the SMALLER of the bracketed figure and the
+        # clean step time of the timed loop (then a lower bound on the rate: the step also holds the
+        # posterior / projection kernels).
+        step_ms_clean = loop_s * 1e3 / T
+        conv_ms_step_events = conv_ms / diff_min(T)
+        conv_ms_step = min(conv_ms_step_events, step_ms_clean)
+        achieved = (conv_flops / diff_min(T)) / (conv_ms_step * 1e-3) / 1e12
         traffic, traffic_note = None, ""
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 table = json.load(open(tpath))
                 key = workload if precision == "fp32" else workload + ":" + precision
-                if key not in table and workload.endswith("t500_b256"):
+                if key not in table and workload.endswith("noproj_t500_b256"):
                     # config 3 launches exactly the conv kernels of config 2 (same net, same batch);
                     # the projection kernel is not a conv launch
                     key = "pointmaze_b256" if precision == "fp32" else "pointmaze_b256:" + precision
@@ -285,9 +293,13 @@ def main() -> None:
             "traffic_source": ("profiles/traffic.json (rocprofv3 PMC pass of this workload; not re-measured in this run)"
                                + traffic_note) if traffic is not None else None,
             "launches_per_denoise_step": launches / diff_min(T),
-            "avg_launch_us": conv_ms * 1e3 / max(launches, 1),
+            "avg_launch_us": conv_ms_step * 1e3 / max(launches / diff_min(T), 1),
             "flops_per_launch": conv_flops / max(launches, 1),
-            "conv_ms_per_denoise_step": conv_ms / diff_min(T),
+            "conv_ms_per_denoise_step": conv_ms_step,
+            "conv_ms_per_denoise_step_event_pass": conv_ms_step_events,
+            "achieved_source": ("HIP events around each denoiser evaluation's conv launches"
+                                if conv_ms_step_events <= step_ms_clean else
+                                "clean step time of the timed loop (the event pass ran slower than the step: lower bound)"),
             "whole_step_tflops": f * batch / step_s / 1e12,
             "hbm_model_bytes_per_denoise_step": hbm_floor,
             "hbm_frac": hbm_floor / step_s / (PEAK_HBM_GBS * 1e9),
@@ -465,7 +477,8 @@ def main() -> None:
         line = {
             "metric": head["metric"], "value": head["value"], "unit": "plans/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16x3 (split-f16 operand pairs, f32 accumulate)",
             "data": "synthetic", "config": head["config"], "roofline": head["roofline"],
             "cpu_baseline": head["cpu_baseline"], "alt_precision": head.get("alt_precision"),
             "configs": configs,

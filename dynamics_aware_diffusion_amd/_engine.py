@@ -335,6 +335,7 @@ class HipEngine:
                 raise RuntimeError("noise_stack must be (n_steps, B, H, td)")
         pa, alphas = None, None
         if projection is not None:
+            projection._check_x(x)
             pa = C.byref(projection.args)
             alphas = (C.c_float * self.n_timesteps)(*[float(a) for a in proj_alphas])
         ws = self.workspace(B)
@@ -355,10 +356,13 @@ class HipEngine:
     # ------------------------------------------------------------------ test / tuning hooks
     def debug_set_tile(self, cfg: int) -> None:
         """Force a conv tile (0..7), -1 = heuristic, 100+cfg / 99 = same without grid split-K."""
-        _check(self.lib, self.lib.dad_debug_set_tile(self._h, int(cfg)))
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_debug_set_tile(self._h, int(cfg)))
 
     def debug_set_option(self, name: str, value: int) -> None:
-        _check(self.lib, self.lib.dad_debug_set_option(self._h, name.encode(), int(value)))
+        # (the entry point synchronises the CURRENT device before dropping captured loops)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_debug_set_option(self._h, name.encode(), int(value)))
 
     def read_table(self, which: str, t: int) -> torch.Tensor:
         """Row t of a per-timestep table (see DAD_TABLE_* in include/dad.h), as a CPU tensor."""
@@ -417,11 +421,32 @@ class ProjectionState:
         a.state_dim, a.observation_dim, a.action_dim = state_dim, observation_dim, action_dim
         self.args = a
         self.device = dev
+        self.D = int(self.P.shape[0])
+        if self.P.dim() != 2 or self.P.shape[1] != self.D:
+            raise ValueError(f"projection matrix must be square, got {tuple(self.P.shape)}")
+        if self.obs_mean.numel() != observation_dim or self.obs_std.numel() != observation_dim \
+                or self.act_mean.numel() != action_dim or self.act_std.numel() != action_dim:
+            raise ValueError("normaliser statistics do not match observation_dim / action_dim")
+
+    def _check_x(self, x: torch.Tensor) -> None:
+        """The kernel derives D = (H+1) n + H m from x's horizon and indexes P[D, D] with it: a batch
+        with another horizon or transition width would read P out of bounds (the reference raises a
+        matmul shape error, guides/policies.py:451, losses/__init__.py:181)."""
+        _require_device(x, "x")
+        a = self.args
+        if x.dim() != 3 or x.shape[2] != a.observation_dim + a.action_dim:
+            raise RuntimeError(f"x must be (B, H, {a.observation_dim + a.action_dim}), got {tuple(x.shape)}")
+        D = (int(x.shape[1]) + 1) * a.state_dim + int(x.shape[1]) * a.action_dim
+        if D != self.D:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.shape[0]}x{D} and "
+                               f"{self.D}x{self.D}): the projector was built for another horizon")
+        if x.device != self.P.device:
+            raise RuntimeError(f"x is on {x.device}, the projector on {self.P.device}")
 
     def violation(self, x: torch.Tensor) -> torch.Tensor:
         """Per-row squared distance from the dynamics-consistent subspace, physical units
         (ProjectionLoss.compute, losses/__init__.py:161-186, before its mean)."""
-        _require_device(x, "x")
+        self._check_x(x)
         out = torch.empty(int(x.shape[0]), dtype=torch.float32, device=x.device)
         lib = load_library()
         with torch.cuda.device(self.device):
@@ -431,7 +456,7 @@ class ProjectionState:
         return out
 
     def apply(self, x: torch.Tensor, alpha: float) -> None:
-        _require_device(x, "x")
+        self._check_x(x)
         lib = load_library()
         with torch.cuda.device(self.device):
             _check(lib, lib.dad_project(C.byref(self.args), float(alpha), x.data_ptr(),

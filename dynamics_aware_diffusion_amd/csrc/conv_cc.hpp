@@ -166,8 +166,8 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
                 for (int q = 0; q < CC_MAX_SLABS; ++q) rp[q] = ldg4(s.rslab + (long)min(q, nrs - 1) * sstride + off[k]);
                 rb = ldg4(s.rbias + c);
             }
-            // masks instead of branches, so that no load can be sunk under a condition
-            const float mt_ = has_t ? 1.0f : 0.0f, mr_ = has_r ? 1.0f : 0.0f, md_ = RIDE ? 1.0f : 0.0f;
+            // selects instead of branches (no load can be sunk under a condition) and instead of 0 / 1
+            // multipliers (0 * Inf of a stand-in operand would poison the sum)
             float4 r = rp[0];
 #pragma unroll
             for (int q = 1; q < CC_MAX_SLABS; ++q) {
@@ -187,11 +187,13 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
                     }
                 }
             }
+            const float4 ts = has_t ? tv : zero4, rs = has_r ? rv : zero4;
+            const float4 ds = RIDE ? make_float4(r.x + rb.x, r.y + rb.y, r.z + rb.z, r.w + rb.w) : zero4;
             float4 e;
-            e.x = tv.x * mt_ + rv.x * mr_ + (r.x + rb.x) * md_;
-            e.y = tv.y * mt_ + rv.y * mr_ + (r.y + rb.y) * md_;
-            e.z = tv.z * mt_ + rv.z * mr_ + (r.z + rb.z) * md_;
-            e.w = tv.w * mt_ + rv.w * mr_ + (r.w + rb.w) * md_;
+            e.x = (ts.x + rs.x) + ds.x;
+            e.y = (ts.y + rs.y) + ds.y;
+            e.z = (ts.z + rs.z) + ds.z;
+            e.w = (ts.w + rs.w) + ds.w;
             ex[k] = e;
             float4 a = part[0];
 #pragma unroll

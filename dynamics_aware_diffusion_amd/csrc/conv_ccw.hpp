@@ -85,22 +85,26 @@ __device__ __forceinline__ void ccw_reduce(const CcSrc& s, const CcwElem<RIDE>& 
 #pragma unroll
     for (int k = 1; k < CC_MAX_SLABS; ++k)
         if (k < s.nsl) { a.x += e.part[k].x; a.y += e.part[k].y; a.z += e.part[k].z; a.w += e.part[k].w; }
-    const float mb = s.bias != nullptr ? 1.0f : 0.0f;
-    v.x = fmaf(e.b.x, mb, a.x); v.y = fmaf(e.b.y, mb, a.y); v.z = fmaf(e.b.z, mb, a.z); v.w = fmaf(e.b.w, mb, a.w);
-    const float mt_ = s.temb != nullptr ? 1.0f : 0.0f, mr_ = s.res != nullptr ? 1.0f : 0.0f;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    float md_ = 0.0f;
+    // absent operands were loaded from some valid address: cancelled with selects (v_cndmask), not
+    // multiplied by 0 — 0 * Inf would carry a non-finite word of an unrelated tensor into the sums
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bb = s.bias != nullptr ? e.b : zero4;
+    v.x = bb.x + a.x; v.y = bb.y + a.y; v.z = bb.z + a.z; v.w = bb.w + a.w;
+    const float4 tv = s.temb != nullptr ? e.tv : zero4, rv = s.res != nullptr ? e.rv : zero4;
+    float4 r = zero4;
+    bool has_d = false;
     if constexpr (RIDE) {
-        md_ = s.rslab != nullptr ? 1.0f : 0.0f;
+        has_d = s.rslab != nullptr;
         r = e.rp[0];
 #pragma unroll
         for (int k = 1; k < CC_MAX_SLABS; ++k)
             if (s.rslab != nullptr && k < s.nrs) { r.x += e.rp[k].x; r.y += e.rp[k].y; r.z += e.rp[k].z; r.w += e.rp[k].w; }
     }
-    ex.x = e.tv.x * mt_ + e.rv.x * mr_ + (r.x + e.rb.x) * md_;
-    ex.y = e.tv.y * mt_ + e.rv.y * mr_ + (r.y + e.rb.y) * md_;
-    ex.z = e.tv.z * mt_ + e.rv.z * mr_ + (r.z + e.rb.z) * md_;
-    ex.w = e.tv.w * mt_ + e.rv.w * mr_ + (r.w + e.rb.w) * md_;
+    const float4 d = has_d ? make_float4(r.x + e.rb.x, r.y + e.rb.y, r.z + e.rb.z, r.w + e.rb.w) : zero4;
+    ex.x = (tv.x + rv.x) + d.x;
+    ex.y = (tv.y + rv.y) + d.y;
+    ex.z = (tv.z + rv.z) + d.z;
+    ex.w = (tv.w + rv.w) + d.w;
 }
 
 // grid = (K slices, M / 32, N tiles of NR rows), 8 waves.  Host contract (cc_plan): weight image in

@@ -126,6 +126,9 @@ struct ConvParams {
     int32_t wtaps;       // tap slots per (chunk, granule) of the weight image (TAPS, or TAPS + 1)
     const float* rbias;  // [M] residual-conv bias
     float* rdst;         // [B*Lout][M] residual-conv output
+    // training forward (dad_unet_forward_train): what the backward pass needs of a GroupNorm'd conv
+    float* pre;          // [B*Lout][M] conv + bias BEFORE the normalisation, or nullptr
+    float* stats;        // [B][M / cpg][2] (mean, rstd) of every (sample, group) pair, or nullptr
     float* slab;         // [tiles][kslices][BN*BM] fp32 partial tiles (workspace)
     unsigned* counters;  // [tiles] arrival tickets, zero between launches
 #ifdef DAD_STAMPS
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         res4[k] = ldg4(has_res ? p.res + max(eoff[k], 0) : p.bias + em);                         \
     }
     // Every parameter load is UNCONDITIONAL: an absent operand reads the bias row instead and is
-    // masked where it is used (tmask / rmask below).  A load under `if (p.gamma)` made hipcc copy the
+    // cancelled by a select where it is used (has_temb / has_res below).  A load under `if (p.gamma)` made hipcc copy the
     // loaded register at the end of the conditional block (a phi), with an s_waitcnt in front of the
     // copy that drained the stage loads issued before it: one exposed memory round trip (~0.6 us)
     // in the prologue of every GroupNorm'd launch (found with -DDAD_STAMPS_PROLOGUE + the ISA).
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     const float* const bptr = has_gn ? p.beta : p.bias;
     const float* const tptr = p.temb != nullptr ? p.temb : p.bias;
     const bool has_res = p.res != nullptr && !p.interleave;
-    const float tmask = p.temb != nullptr ? 1.0f : 0.0f, rmask = has_res ? 1.0f : 0.0f;
+    const bool has_temb = p.temb != nullptr;
     DAD_PSTAMP(7);
     if (EARLY_PARAMS) { DAD_FETCH_PARAMS() }   // younger than the stage loads: not waited with them
     DAD_PSTAMP(1);
@@ -809,6 +812,13 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         y[k][0] += bias4[k].x; y[k][1] += bias4[k].y; y[k][2] += bias4[k].z; y[k][3] += bias4[k].w;
     }
 
+    if (p.pre != nullptr) {                            // (block-uniform: stores only, no load sits under it)
+#pragma unroll
+        for (int k = 0; k < F4PL; ++k)
+            if (eoff[k] >= 0)
+                *reinterpret_cast<float4*>(p.pre + eoff[k]) = make_float4(y[k][0], y[k][1], y[k][2], y[k][3]);
+    }
+
     if (has_gn) {
         const float inv_cnt = 1.0f / (float)(cnt4 * 4);
         const int width = lpp < 64 ? lpp : 64;
@@ -840,6 +850,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #pragma unroll
             for (int c = 0; c < 4; ++c) { const float d = y[k][c] - mean; sq += d * d; }
         const float rstd = 1.0f / sqrtf(pair_sum(sq, 1) * inv_cnt + 1e-5f);
+        if (p.stats != nullptr && lp == 0 && eoff[0] >= 0) {      // one lane per (sample, group) pair
+            float* st = p.stats + ((long)(s0 + ps) * (M >> (31 - __clz(cpg))) + ((m0 >> (31 - __clz(cpg))) + pg)) * 2;
+            st[0] = mean; st[1] = rstd;
+        }
 #pragma unroll
         for (int k = 0; k < F4PL; ++k) {
             y[k][0] = mish_fast_f32((y[k][0] - mean) * rstd * gam4[k].x + bet4[k].x);
@@ -852,10 +866,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #pragma unroll
     for (int k = 0; k < F4PL; ++k) {
         if (eoff[k] < 0) continue;
-        // tmask, rmask in {0, 1}: fma(temb, 1, res * 1) is temb + res with one rounding, as before
-        const float4 o4 =
-            make_float4(y[k][0] + fmaf(temb4[k].x, tmask, res4[k].x * rmask), y[k][1] + fmaf(temb4[k].y, tmask, res4[k].y * rmask),
-                        y[k][2] + fmaf(temb4[k].z, tmask, res4[k].z * rmask), y[k][3] + fmaf(temb4[k].w, tmask, res4[k].w * rmask));
+        // absent operands were loaded from the bias row: cancelled with a select (v_cndmask), not a
+        // multiply by 0 — 0 * Inf would turn a non-finite word of an unrelated tensor into NaN here
+        const float4 t4 = has_temb ? temb4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r4 = has_res ? res4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o4 = make_float4(y[k][0] + (t4.x + r4.x), y[k][1] + (t4.y + r4.y),
+                                      y[k][2] + (t4.z + r4.z), y[k][3] + (t4.w + r4.w));
         // write-through: nothing of the tile is left dirty in this XCD's L2 for the end-of-kernel
         // release to write back (+0.5 % at batch 256, +0.7 % on Door; same bytes)
         store_f4_sc1(p.dst + eoff[k], o4);

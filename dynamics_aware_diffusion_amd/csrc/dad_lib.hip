@@ -24,6 +24,7 @@
 #include "pointwise.hpp"
 #include "conv_cc.hpp"
 #include "conv_ccw.hpp"
+#include "train_bwd.hpp"
 
 using namespace dadhost;
 
@@ -70,6 +71,7 @@ struct dad_model : HostModel {
     float* d_final_b = nullptr;
     uint64_t* d_rng = nullptr;
     unsigned* d_counters = nullptr;   // split-K arrival tickets (zero between launches)
+    float* d_zero = nullptr;          // zeros: bias row of the data-gradient launches (training)
     std::vector<void*> owned;         // every hipMalloc to free
     // All parameters, tables and flags live in ONE device allocation: a conv launch touches a
     // handful of pages instead of one page per tensor (cold address translations used to cost
@@ -121,7 +123,11 @@ void free_device(dad_model* m) {
     m->d_final_w = m->d_final_b = nullptr;
     m->d_rng = nullptr;
     m->d_counters = nullptr;
-    for (auto& op : m->plan.convs) op.d_w = op.d_bias = op.d_gamma = op.d_beta = op.d_rbias = nullptr;
+    m->d_zero = nullptr;
+    for (Plan* plan : {&m->plan, &m->tplan})
+        for (auto& op : plan->convs) op.d_w = op.d_bias = op.d_gamma = op.d_beta = op.d_rbias = nullptr;
+    for (auto& b : m->bconvs) for (int k = 0; k < b.n; ++k) b.op[k].d_w = b.op[k].d_bias = nullptr;
+    m->bfinal.d_w = m->bfinal.d_bias = nullptr;
 }
 
 // ---------------------------------------------------------------------- kernel registry
@@ -148,6 +154,8 @@ template <int CFG>
 void reg_tile(KernTable& t) {
     reg_kernel<CFG, 5, 1, false, false, false>(t);
     reg_kernel<CFG, 3, 2, false, false, false>(t);
+    if constexpr (Tile<CFG>::KC >= 16)                      // backward of Upsample1d: 5-tap stride-2 conv
+        reg_kernel<CFG, 5, 2, false, false, false>(t);
     reg_kernel<CFG, 2, 1, false, false, false>(t);
     reg_kernel<CFG, 1, 1, false, false, false>(t);
     if constexpr (Tile<CFG>::KC >= 16) {
@@ -231,6 +239,10 @@ int configure_kernels() {
                         HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
@@ -239,10 +251,24 @@ int configure_kernels() {
     return DAD_OK;
 }
 
-int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int batch, int t,
-             hipStream_t st, const int32_t* trow = nullptr) {
+// Operands of one conv-GEMM launch as raw pointers (the forward plans name buffers; the backward walk
+// passes gradient tensors).
+struct ConvIO {
+    const float* src0 = nullptr; const float* src1 = nullptr;
+    float* dst = nullptr; const float* res = nullptr; float* rdst = nullptr;
+    const float* temb = nullptr; const int32_t* trow = nullptr;
+    float* pre = nullptr; float* stats = nullptr;      // training forward: pre-normalisation output, pair statistics
+    float* slab = nullptr;                             // split-K scratch
+};
+int launch_conv(dad_model* m, const ConvOp& op, int batch, const ConvIO& io, hipStream_t st);
+
+// `plan`: m->plan (sampling: buffers shared by lifetime) or m->tplan (training: every tensor kept, plus
+// the pre-activation / statistics buffers of the GroupNorm'd convs).  `temb_rows`: (B, temb_width) time
+// projections of the training forward (indexed through trow), instead of the per-timestep table.
+int run_conv(dad_model* m, const Plan& plan, const ConvOp& op, const float* xext, float* ws, int batch, int t,
+             hipStream_t st, const int32_t* trow = nullptr, const float* temb_rows = nullptr) {
     auto buf = [&](int id) -> float* {
-        return id >= 0 ? ws + m->plan.bufs[id].offset * (long)batch : nullptr;
+        return id >= 0 ? ws + plan.bufs[id].offset * (long)batch : nullptr;
     };
     if (op.cat0 >= 0) {     // rows of [cat0 | cat1] side by side into the residual buffer
         const long rows = (long)batch * op.Lout;
@@ -251,18 +277,37 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
                            buf(op.res), buf(op.cat0), buf(op.cat1), rows, op.cat_c0, op.cat_c1);
         HIP_TRY(hipGetLastError());
     }
+    ConvIO io;
+    io.src0 = op.src0 == -2 ? xext : buf(op.src0);
+    io.src1 = buf(op.src1);
+    // shared timestep: row t of the table; per-row timesteps: row 0 + trow[b] * stride in the kernel
+    if (op.temb_off >= 0)
+        io.temb = temb_rows != nullptr ? temb_rows + op.temb_off
+                                       : m->d_temb_table + (trow ? 0L : (long)t * m->plan.temb_width) + op.temb_off;
+    // per-row timesteps only where there is a time embedding to index: the kernels' fallback operand
+    // for an absent embedding is the bias row, which must not be offset by trow[b] * stride
+    io.trow = io.temb != nullptr ? trow : nullptr;
+    io.res = op.res == -2 ? xext : buf(op.res);       // identity residual of the trajectory itself (td == C)
+    io.dst = buf(op.dst);
+    io.rdst = buf(op.rdst);
+    io.pre = buf(op.pre); io.stats = buf(op.stats);
+    io.slab = ws + plan.floats_per_sample * (long)batch;     // scratch behind the activations
+    return launch_conv(m, op, batch, io, st);
+}
+
+int launch_conv(dad_model* m, const ConvOp& op, int batch, const ConvIO& io, hipStream_t st) {
     LaunchGeom g;
     int rc = plan_launch(*m, op, batch, g);
     if (rc != DAD_OK) return rc;
     ConvParams p{};
-    p.src0 = op.src0 == -2 ? xext : buf(op.src0);
-    p.src1 = buf(op.src1);
+    p.src0 = io.src0;
+    p.src1 = io.src1;
     p.w = op.d_w; p.bias = op.d_bias; p.gamma = op.d_gamma; p.beta = op.d_beta;
-    // shared timestep: row t of the table; per-row timesteps: row 0 + trow[b] * stride in the kernel
-    p.temb = op.temb_off >= 0 ? m->d_temb_table + (trow ? 0L : (long)t * m->plan.temb_width) + op.temb_off : nullptr;
-    p.trow = trow; p.temb_stride = m->plan.temb_width;
-    p.res = op.res == -2 ? xext : buf(op.res);       // identity residual of the trajectory itself (td == C)
-    p.dst = buf(op.dst);
+    p.temb = io.temb;
+    p.trow = io.trow; p.temb_stride = m->plan.temb_width;
+    p.res = io.res;
+    p.dst = io.dst;
+    p.pre = io.pre; p.stats = io.stats;
     p.cin0 = op.cin0; p.cin1 = op.cin1; p.cin_pad = op.cin_pad;
     p.M = op.M; p.cpg = op.norm.empty() ? 0 : op.cout / 8;
     p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout; p.lshift = ilog2(op.Lout);
@@ -272,20 +317,23 @@ int run_conv(dad_model* m, const ConvOp& op, const float* xext, float* ws, int b
     p.xcd_gn = g.xcd_gn; p.xcd_mts = g.xcd_mts; p.xcd_ntn = g.xcd_ntn;
     p.kslices = g.split.kslices;
     p.chunks_per_slice = g.split.chunks_per_slice;
-    p.slab = ws + m->plan.floats_per_sample * (long)batch;     // scratch behind the activations
+    p.slab = io.slab;
     p.counters = m->d_counters;
     p.c1 = op.c1; p.c2 = op.c2;
     p.xswz = g.xswz;
     p.wtaps = op.wtaps();
     p.rbias = g.fused ? op.d_rbias : nullptr;
-    p.rdst = g.fused ? buf(op.rdst) : nullptr;
+    p.rdst = g.fused ? io.rdst : nullptr;
+    if (g.split.kslices > 1 && io.slab == nullptr)
+        return fail(DAD_E_WORKSPACE, "%s: split-K launch without scratch", op.name.c_str());
     static const bool trace = getenv("DAD_TRACE_TILES") != nullptr;     // tuning aid
     if (trace)
         fprintf(stderr, "[dad] %-34s B=%d M=%d K=%dx%d L=%d tile=%d (%dx%d SK%d) kslices=%d%s\n", op.name.c_str(),
                 batch, op.M, op.taps, op.cin0 + op.cin1, op.Lout, g.cfg, kTiles[g.cfg].BM, kTiles[g.cfg].BN,
                 kTiles[g.cfg].SK, g.split.kslices, g.fused ? " +res1x1" : "");
 #ifdef DAD_STAMPS
-    p.stamps = g_stamps ? g_stamps + (size_t)(&op - &m->plan.convs[0]) * 4096 * 8 : nullptr;
+    p.stamps = (g_stamps && &op >= &m->plan.convs[0] && &op < &m->plan.convs[0] + m->plan.convs.size())
+                   ? g_stamps + (size_t)(&op - &m->plan.convs[0]) * 4096 * 8 : nullptr;
 #endif
     const auto& table = kernel_table();
     const auto it = table.find(KernKey(g.cfg, op.taps, op.stride, op.x3, op.bdir, g.ragged, g.fused));
@@ -384,7 +432,8 @@ int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float*
 }
 
 int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStream_t st,
-             const int32_t* trow = nullptr, const CcPlan* cc = nullptr) {
+             const int32_t* trow = nullptr, const CcPlan* cc = nullptr, bool train = false,
+             const float* temb_rows = nullptr) {
     // Profiling brackets the whole run of conv-GEMM launches of one denoiser evaluation with
     // ONE pair of HIP events on the launch stream (events between individual launches would
     // break the back-to-back dispatch they are meant to time).
@@ -401,7 +450,8 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
         ++m->ev_used;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    const std::vector<ConvOp>& convs = m->plan.convs;
+    const Plan& plan = train ? m->tplan : m->plan;
+    const std::vector<ConvOp>& convs = plan.convs;
     if (cc != nullptr) {                                  // small batch: consumer-combine kernels
         for (size_t i = 0; i < convs.size(); ++i) {
             if (m->profile) m->prof_flops += convs[i].flops_per_sample * batch;
@@ -418,7 +468,7 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
         const bool rides = op.rider_of >= 0 && fused_at(*m, convs[op.rider_of], batch);
         if (m->profile) m->prof_flops += op.flops_per_sample * batch;
         if (rides) continue;
-        const int rc = run_conv(m, op, x, ws, batch, t, st, trow);
+        const int rc = run_conv(m, plan, op, x, ws, batch, t, st, trow, temb_rows);
         if (rc != DAD_OK) return rc;
         if (m->profile) ++m->prof_launches;
     }
@@ -428,10 +478,11 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
 
 int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const dad_step_args* a,
               int x_out_disabled, float* eps_only, float* ws, hipStream_t st,
-              bool seed_from_device = false, const CcPlan* cc = nullptr) {
+              bool seed_from_device = false, const CcPlan* cc = nullptr, bool train = false) {
     const dad_cfg& c = m->cfg;
     dad::FinalParams p{};
-    p.act = ws + m->plan.bufs[m->plan.final_act].offset * (long)batch;
+    const Plan& plan = train ? m->tplan : m->plan;
+    p.act = ws + plan.bufs[plan.final_act].offset * (long)batch;
     p.w = m->d_final_w; p.bias = m->d_final_b;
     p.dim = c.dim; p.td = c.transition_dim; p.B = batch; p.H = c.horizon;
     p.predict_epsilon = c.predict_epsilon; p.clip_denoised = c.clip_denoised;
@@ -638,6 +689,27 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
         }
     }
     int rc;
+    for (size_t i = 0; i < m->plan.convs.size(); ++i) {        // the training plan launches the same images
+        const ConvOp& a = m->plan.convs[i];
+        ConvOp& b = m->tplan.convs[i];
+        b.d_w = a.d_w; b.d_bias = a.d_bias; b.d_gamma = a.d_gamma; b.d_beta = a.d_beta; b.d_rbias = a.d_rbias;
+        b.c1 = a.c1; b.c2 = a.c2;
+    }
+    if (m->training) {
+        if (const char* why = training_refusal(*m)) return fail(DAD_E_INVALID, "training: %s", why);
+        std::vector<float> zeros((size_t)std::max(m->max_bwd_m, 2 * m->max_cout) + 64, 0.0f);
+        if ((rc = upload(m, zeros, &m->d_zero)) != DAD_OK) return rc;
+        std::vector<float> img;
+        for (size_t i = 0; i < m->bconvs.size(); ++i)
+            for (int k = 0; k < m->bconvs[i].n; ++k) {
+                if ((rc = pack_bwd_op(m, m->tplan.convs[i], m->bconvs[i], k, img)) != DAD_OK) return rc;
+                if ((rc = upload(m, img, &m->bconvs[i].op[k].d_w)) != DAD_OK) return rc;
+                m->bconvs[i].op[k].d_bias = m->d_zero;
+            }
+        if ((rc = pack_bwd_final(m, img)) != DAD_OK) return rc;
+        if ((rc = upload(m, img, &m->bfinal.d_w)) != DAD_OK) return rc;
+        m->bfinal.d_bias = m->d_zero;
+    }
     if ((rc = upload(m, m->raw["final_conv.1.weight"].data, &m->d_final_w)) != DAD_OK) return rc;
     if ((rc = upload(m, m->raw["final_conv.1.bias"].data, &m->d_final_b)) != DAD_OK) return rc;
 
@@ -834,6 +906,307 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
         it = m->graphs.emplace(key, exec).first;
     }
     HIP_TRY(hipGraphLaunch(it->second, st));
+    return DAD_OK;
+}
+
+// ---------------------------------------------------------------------------------- training
+int dad_model_set_training(dad_model* m, int32_t on) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    if (on) if (const char* why = training_refusal(*m)) return fail(DAD_E_INVALID, "training: %s", why);
+    if ((on != 0) != m->training) m->finalized = false;       // the data-gradient images are packed at finalize
+    m->training = on != 0;
+    return DAD_OK;
+}
+
+int dad_train_grad_count(const dad_model* m, int32_t* count, int64_t* total_floats) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    if (count) *count = (int32_t)m->grad_slots.size();
+    if (total_floats) *total_floats = m->grad_numel;
+    return DAD_OK;
+}
+
+int dad_train_grad_info(const dad_model* m, int32_t i, const char** key, int64_t* offset, int64_t* numel) {
+    if (!m || i < 0 || i >= (int32_t)m->grad_slots.size()) return fail(DAD_E_INVALID, "gradient slot %d out of range", i);
+    if (key) *key = m->grad_slots[i].key.c_str();
+    if (offset) *offset = m->grad_slots[i].offset;
+    if (numel) *numel = m->grad_slots[i].numel;
+    return DAD_OK;
+}
+
+}  // extern "C"  (helpers of the training entry points follow)
+
+namespace {
+
+struct WgradGeom { int spc, ksplit, sps; unsigned gx, gy; size_t lds; };
+WgradGeom wgrad_geom(int M, int Ctot, int B, int Lg, int Lz, int taps, int pad) {
+    WgradGeom g{};
+    g.spc = std::max(1, dad::WG_ROWS / Lg);
+    g.gx = (unsigned)((M + dad::WG_TILE - 1) / dad::WG_TILE);
+    g.gy = (unsigned)((Ctot + dad::WG_TILE - 1) / dad::WG_TILE);
+    const long tiles = (long)g.gx * g.gy;
+    const int chunks = (B + g.spc - 1) / g.spc;
+    int want = (int)std::max(1L, 256 / tiles);
+    want = std::min(want, chunks);
+    g.sps = (chunks + want - 1) / want * g.spc;                // samples per split: whole chunks
+    g.ksplit = (B + g.sps - 1) / g.sps;
+    g.lds = dad::wgrad_lds_floats(g.spc, Lg, Lz, taps, pad) * sizeof(float);
+    return g;
+}
+
+// scratch of dad_unet_backward, in floats: gradient mirror of the training plan | per-sample partial sums
+// | wgrad split slabs | padded d x | staging of a down-sampling conv's data gradient | split-K slabs
+struct TrainScratch { long mirror, part, wslab, dxpad, tmp, bslab, total; };
+TrainScratch train_scratch(const dad_model& m, int B) {
+    TrainScratch t{};
+    const Plan& P = m.tplan;
+    const int H = m.cfg.horizon, td = m.cfg.transition_dim;
+    t.mirror = P.floats_per_sample * (long)B;
+    t.part = 3L * B * m.max_cout;
+    long ws = 0, tmp = 0, bs = 0;
+    auto wg = [&](int M, int C, int Lg, int Lz, int taps, int pad, long numel) {
+        const WgradGeom g = wgrad_geom(M, C, B, Lg, Lz, taps, pad);
+        if (g.ksplit > 1) ws = std::max(ws, (long)g.ksplit * numel);
+    };
+    for (size_t i = 0; i < P.convs.size(); ++i) {
+        const ConvOp& f = P.convs[i];
+        const int cin = f.cin0 + f.cin1;
+        switch (f.kind) {
+            case CONV_K5: case CONV_1X1: wg(f.cout, cin, f.Lin, f.Lin, f.taps, f.taps / 2, (long)f.cout * cin * f.taps); break;
+            case CONV_DOWN: wg(f.cout, cin, f.Lout, f.Lin, 3, 1, (long)f.cout * cin * 3);
+                tmp = std::max(tmp, (long)B * f.Lin * cin); break;
+            case CONV_UP: wg(cin, f.cout, f.Lin, 2 * f.Lin, 4, 1, (long)cin * f.cout * 4); break;
+        }
+        for (int k = 0; k < m.bconvs[i].n; ++k) {
+            const ConvOp& b = m.bconvs[i].op[k];
+            const int cfg = choose_tile(m, b, B);
+            if (cfg >= 0) bs = std::max(bs, plan_split(m, b, cfg, B).slab_floats);
+        }
+    }
+    wg(td, m.cfg.dim, H, H, 1, 0, (long)td * m.cfg.dim);
+    {
+        const int cfg = choose_tile(m, m.bfinal, B);
+        if (cfg >= 0) bs = std::max(bs, plan_split(m, m.bfinal, cfg, B).slab_floats);
+    }
+    t.wslab = ws; t.tmp = tmp; t.bslab = bs;
+    t.dxpad = (long)B * H * round_up(td, 32);
+    auto al = [](long v) { return (v + 63) / 64 * 64; };
+    t.mirror = al(t.mirror); t.part = al(t.part); t.wslab = al(t.wslab); t.dxpad = al(t.dxpad);
+    t.tmp = al(t.tmp); t.bslab = al(t.bslab);
+    t.total = t.mirror + t.part + t.wslab + t.dxpad + t.tmp + t.bslab;
+    return t;
+}
+
+size_t train_saved_bytes(const dad_model& m, int B) {
+    return ((size_t)m.tplan.floats_per_sample * (size_t)B + (size_t)slab_floats_for(m, B)) * sizeof(float);
+}
+
+__global__ void slice_cols_kernel(float* dst, const float* src, long rows, int cols, int ld) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long r = i / cols;
+    dst[i] = src[r * ld + (i - r * cols)];
+}
+
+int check_train(const dad_model* m, int batch) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    if (!m->training) return fail(DAD_E_STATE, "dad_model_set_training(m, 1) has not been called");
+    if (!m->finalized) return fail(DAD_E_STATE, "dad_model_finalize has not been called");
+    if (batch <= 0) return fail(DAD_E_INVALID, "batch must be positive (got %d)", batch);
+    return DAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dad_train_workspace_bytes(const dad_model* m, int32_t batch, size_t* saved_bytes, size_t* scratch_bytes) {
+    if (!m || batch <= 0) return fail(DAD_E_INVALID, "bad argument");
+    if (saved_bytes) *saved_bytes = train_saved_bytes(*m, batch);
+    if (scratch_bytes) *scratch_bytes = (size_t)train_scratch(*m, batch).total * sizeof(float);
+    return DAD_OK;
+}
+
+int dad_unet_forward_train(dad_model* m, const float* x, const int32_t* row_index, const float* temb_rows,
+                           float* out, int32_t batch, void* saved, size_t saved_bytes, dad_stream_t stream) {
+    int rc = check_train(m, batch);
+    if (rc != DAD_OK) return rc;
+    if (!x || !row_index || !temb_rows || !out || !saved) return fail(DAD_E_INVALID, "null pointer");
+    if (saved_bytes < train_saved_bytes(*m, batch))
+        return fail(DAD_E_WORKSPACE, "saved-activation buffer has %zu bytes, batch %d needs %zu", saved_bytes, batch,
+                    train_saved_bytes(*m, batch));
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_unet(m, x, 0, batch, (float*)saved, st, row_index, nullptr, true, temb_rows)) != DAD_OK) return rc;
+    return run_final(m, nullptr, x, 0, batch, nullptr, 1, out, (float*)saved, st, false, nullptr, true);
+}
+
+int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d_x, float* d_temb_rows, float* grads,
+                      int32_t batch, void* saved_v, size_t saved_bytes, void* scratch_v, size_t scratch_bytes,
+                      dad_stream_t stream) {
+    int rc = check_train(m, batch);
+    if (rc != DAD_OK) return rc;
+    if (!x || !d_out || !d_temb_rows || !grads || !saved_v || !scratch_v) return fail(DAD_E_INVALID, "null pointer");
+    const int B = batch;
+    const TrainScratch ts = train_scratch(*m, B);
+    if (saved_bytes < train_saved_bytes(*m, B) || scratch_bytes < (size_t)ts.total * sizeof(float))
+        return fail(DAD_E_WORKSPACE, "backward workspaces too small (saved %zu / %zu, scratch %zu / %zu bytes)", saved_bytes,
+                    train_saved_bytes(*m, B), scratch_bytes, (size_t)ts.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    const Plan& P = m->tplan;
+    const std::vector<ConvOp>& convs = P.convs;
+    const dad_cfg& c = m->cfg;
+    const int H = c.horizon, td = c.transition_dim, tdp = round_up(td, 32), maxC = m->max_cout;
+    float* const saved = (float*)saved_v;
+    float* const mirror = (float*)scratch_v;
+    float* const part = mirror + ts.mirror;
+    float* const wslab = part + ts.part;
+    float* const dxpad = wslab + ts.wslab;
+    float* const tmp = dxpad + ts.dxpad;
+    float* const bslab = tmp + ts.tmp;
+    auto act = [&](int id) -> float* { return id >= 0 ? saved + P.bufs[id].offset * (long)B : nullptr; };
+    std::vector<int> alias(P.bufs.size(), -1);       // gradient of this buffer IS the gradient of that one
+    std::vector<char> written(P.bufs.size(), 0);
+    auto resolve = [&](int id) { while (alias[id] >= 0) id = alias[id]; return id; };
+    auto grd = [&](int id) -> float* { return mirror + P.bufs[resolve(id)].offset * (long)B; };
+    std::vector<int> owner(P.bufs.size(), -1);
+    for (size_t i = 0; i < convs.size(); ++i) owner[convs[i].dst] = (int)i;
+    bool dx_written = false;
+    auto G = [&](const std::string& key) -> float* { return grads + m->grad_at.at(key); };
+
+    // y += x over n floats (n a multiple of 4), or y = x when y holds nothing yet
+    auto accumulate = [&](float* y, const float* xs, long n, bool have) -> int {
+        if (!have) { HIP_TRY(hipMemcpyAsync(y, xs, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st)); return DAD_OK; }
+        const long n4 = n / 4;
+        hipLaunchKernelGGL(dad::add_inplace_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, xs, n4);
+        HIP_TRY(hipGetLastError());
+        return DAD_OK;
+    };
+    auto col_sums = [&](float* out, const float* p, int C) -> int {
+        hipLaunchKernelGGL(dad::col_sums_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, out, p, B, C, C);
+        HIP_TRY(hipGetLastError());
+        return DAD_OK;
+    };
+    auto bias_grad = [&](float* out, const float* g, int rows_per_sample, int C) -> int {
+        hipLaunchKernelGGL(dad::row_partial_sums_kernel, dim3(B), dim3(256), 0, st, part, g, rows_per_sample, C, C);
+        HIP_TRY(hipGetLastError());
+        return col_sums(out, part, C);
+    };
+    auto wgrad = [&](const float* Gp, int ldg, int M, const float* Z0, int C0, const float* Z1, int C1, float* out,
+                     int taps, int stride, int pad, int Lg, int Lz) -> int {
+        const WgradGeom g = wgrad_geom(M, C0 + C1, B, Lg, Lz, taps, pad);
+        if (g.lds > dad::kLdsBytes) return fail(DAD_E_INVALID, "wgrad: a chunk of %d x %d rows does not fit LDS", g.spc, Lz);
+        dad::WgradParams p{};
+        p.G = Gp; p.ldg = ldg; p.M = M;
+        p.Z0 = Z0; p.ldz0 = C0; p.C0 = C0; p.Z1 = Z1; p.ldz1 = C1; p.C1 = C1;
+        p.out_numel = (long)M * (C0 + C1) * taps;
+        p.out = g.ksplit > 1 ? wslab : out;
+        p.B = B; p.Lg = Lg; p.Lz = Lz; p.lg_shift = ilog2(Lg); p.stride = stride; p.pad = pad;
+        p.ksplit = g.ksplit; p.samples_per_split = g.sps; p.spc = g.spc;
+        const dim3 grid(g.gx, g.gy, (unsigned)g.ksplit);
+        switch (taps) {
+            case 1: hipLaunchKernelGGL(dad::conv_wgrad<1>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
+            case 3: hipLaunchKernelGGL(dad::conv_wgrad<3>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
+            case 4: hipLaunchKernelGGL(dad::conv_wgrad<4>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
+            case 5: hipLaunchKernelGGL(dad::conv_wgrad<5>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
+            default: return fail(DAD_E_INVALID, "wgrad: %d taps", taps);
+        }
+        HIP_TRY(hipGetLastError());
+        if (g.ksplit > 1) {
+            hipLaunchKernelGGL(dad::sum_slabs_kernel, dim3((unsigned)((p.out_numel + 255) / 256)), dim3(256), 0, st, out,
+                               wslab, p.out_numel, g.ksplit);
+            HIP_TRY(hipGetLastError());
+        }
+        return DAD_OK;
+    };
+    // data gradient `bop` of dH into buffer `target` (-2: the trajectory), adding to what is there
+    auto dgrad = [&](const ConvOp& bop, const float* dH, int target, long target_floats) -> int {
+        float* dst;
+        bool have;
+        if (target == -2) { dst = dxpad; have = dx_written; dx_written = true; }
+        else { dst = grd(target); have = written[resolve(target)]; written[resolve(target)] = 1; }
+        ConvIO io;
+        io.src0 = dH; io.slab = bslab;
+        if (bop.kind == CONV_UP && have) {                 // the interleaving store has no residual operand
+            io.dst = tmp;
+            int r = launch_conv(m, bop, B, io, st);
+            if (r != DAD_OK) return r;
+            return accumulate(dst, tmp, target_floats, true);
+        }
+        io.dst = dst;
+        io.res = have ? dst : nullptr;
+        return launch_conv(m, bop, B, io, st);
+    };
+
+    // ---- final_conv[1] (1x1, dim -> td; forward in final_posterior_kernel)
+    {
+        if ((rc = bias_grad(G("final_conv.1.bias"), d_out, H, td)) != DAD_OK) return rc;
+        if ((rc = wgrad(d_out, td, td, act(P.final_act), c.dim, nullptr, 0, G("final_conv.1.weight"), 1, 1, 0, H, H)) != DAD_OK)
+            return rc;
+        if ((rc = dgrad(m->bfinal, d_out, P.final_act, (long)B * H * c.dim)) != DAD_OK) return rc;
+    }
+    for (int i = (int)convs.size() - 1; i >= 0; --i) {
+        const ConvOp& f = convs[i];
+        if (!written[resolve(f.dst)])
+            return fail(DAD_E_STATE, "backward: no gradient reached the output of %s", f.name.c_str());
+        const float* gout = grd(f.dst);
+        const int out_rows = f.kind == CONV_UP ? 2 * f.Lout : f.Lout;      // rows per sample of the output
+        const long out_floats = (long)B * out_rows * f.cout;
+        const float* dH = gout;
+        if (!f.norm.empty()) {
+            if (f.res == -2) {                             // identity residual of the trajectory itself (td == C)
+                if ((rc = accumulate(dxpad, gout, out_floats, dx_written)) != DAD_OK) return rc;
+                dx_written = true;
+            } else if (f.res >= 0) {
+                const int q = owner[f.res];
+                const bool conv_out = q >= 0 && convs[q].kind == CONV_1X1 && convs[q].norm.empty();
+                if (conv_out) { alias[f.res] = resolve(f.dst); }         // the 1x1 residual conv's output gradient
+                else {
+                    const int r = resolve(f.res);
+                    if ((rc = accumulate(grd(f.res), gout, out_floats, written[r])) != DAD_OK) return rc;
+                    written[r] = 1;
+                }
+            }
+            dad::GnBwdParams gp{};
+            gp.dA = gout; gp.h = act(f.pre); gp.stats = act(f.stats);
+            gp.gamma = f.d_gamma; gp.beta = f.d_beta;
+            gp.dH = mirror + P.bufs[f.pre].offset * (long)B;
+            gp.part_dgamma = part; gp.part_dbeta = part + (long)B * maxC; gp.part_dbias = part + 2L * B * maxC;
+            gp.dtemb = f.temb_off >= 0 ? d_temb_rows + f.temb_off : nullptr;
+            gp.temb_stride = P.temb_width;
+            gp.C = f.cout; gp.L = f.Lout; gp.cpg = f.cout / 8;
+            hipLaunchKernelGGL(dad::gn_mish_bwd_kernel, dim3(B, 8), dim3(dad::GNB_THREADS), 0, st, gp);
+            HIP_TRY(hipGetLastError());
+            // (the partial arrays are [B][C] with C = this conv's width)
+            if ((rc = col_sums(G(f.norm + ".weight"), gp.part_dgamma, f.cout)) != DAD_OK) return rc;
+            if ((rc = col_sums(G(f.norm + ".bias"), gp.part_dbeta, f.cout)) != DAD_OK) return rc;
+            if ((rc = col_sums(G(f.name + ".bias"), gp.part_dbias, f.cout)) != DAD_OK) return rc;
+            dH = gp.dH;
+        } else {
+            if ((rc = bias_grad(G(f.name + ".bias"), dH, out_rows, f.cout)) != DAD_OK) return rc;
+        }
+        const float* s0 = f.src0 == -2 ? x : act(f.src0);
+        const float* s1 = act(f.src1);
+        float* gw = G(f.name + ".weight");
+        switch (f.kind) {
+            case CONV_K5: case CONV_1X1:
+                rc = wgrad(dH, f.cout, f.cout, s0, f.cin0, s1, f.cin1, gw, f.taps, 1, f.taps / 2, f.Lin, f.Lin); break;
+            case CONV_DOWN:
+                rc = wgrad(dH, f.cout, f.cout, s0, f.cin0, nullptr, 0, gw, 3, 2, 1, f.Lout, f.Lin); break;
+            case CONV_UP:
+                rc = wgrad(s0, f.cin0, f.cin0, dH, f.cout, nullptr, 0, gw, 4, 2, 1, f.Lin, 2 * f.Lin); break;
+        }
+        if (rc != DAD_OK) return rc;
+        const HostModel::BwdConv& b = m->bconvs[i];
+        for (int k = 0; k < b.n; ++k) {
+            const int target = k == 0 ? f.src0 : f.src1;
+            if ((rc = dgrad(b.op[k], dH, target, (long)B * f.Lin * b.c_n[k])) != DAD_OK) return rc;
+        }
+    }
+    if (d_x != nullptr) {
+        if (!dx_written) return fail(DAD_E_STATE, "backward: no gradient reached the trajectory");
+        const long n = (long)B * H * td;
+        hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, dxpad, (long)B * H, td, tdp);
+        HIP_TRY(hipGetLastError());
+    }
     return DAD_OK;
 }
 

@@ -69,6 +69,10 @@ struct ConvOp {
     bool ride = false;       // weight image holds the sixth tap (decided at pack time)
     int rider_of = -1;       // this op is the stand-alone form of convs[rider_of]'s ride
     float c1 = 1.0f, c2 = 0.0f;   // x3: output scales 2^-s and 2^-(s+11)
+    // training plan only (HostModel::tplan): where the forward keeps what the backward pass needs of a
+    // GroupNorm'd conv — its pre-normalisation output (conv + bias) and the (mean, rstd) of every
+    // (sample, group) pair, [8][2] floats per sample
+    int pre = -1, stats = -1;
     // device tensors (owned by the model)
     float* d_w = nullptr;
     float* d_bias = nullptr;
@@ -124,6 +128,9 @@ struct HostModel {
     std::map<std::string, HostTensor> raw;
     std::map<std::string, std::vector<int64_t>> expected;     // key -> shape
     Plan plan;
+    Plan tplan;                                                // the same launches with every tensor in a buffer of
+                                                               // its own (nothing is overwritten before the backward
+                                                               // pass has read it) + pre-activation / statistics buffers
     int precision = DAD_PREC_FP32;                             // dad_model_set_precision
     // tuning / test hooks (dad_debug_set_tile) — per model, nothing process-wide
     int force_tile = -1;
@@ -139,6 +146,22 @@ struct HostModel {
     bool ccw_prefer16 = true;                                  //   two 16-row tiles instead of an LDS-short 32-row one
                                                                //   (measured crossover: batch 16 at H = 32)
     std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo
+    // ---- backward pass (dad_model_set_training): data-gradient launches + the layout of the gradients
+    bool training = false;
+    struct BwdConv {
+        int n = 0;               // data-gradient launches of this forward conv (one per concat source)
+        ConvOp op[2];
+        int c_lo[2] = {0, 0};    // first input channel of the forward conv each one covers
+        int c_n[2] = {0, 0};     // real channels (op.cout is c_n rounded up to 32)
+    };
+    std::vector<BwdConv> bconvs; // parallel to tplan.convs
+    ConvOp bfinal;               // data gradient of final_conv[1] (1x1, transition_dim -> dim)
+    struct GradSlot { std::string key; long offset, numel; };
+    std::vector<GradSlot> grad_slots;        // flat gradient buffer: reference state_dict keys, torch layouts
+    long grad_numel = 0;
+    std::map<std::string, long> grad_at;     // key -> offset
+    int max_cout = 0;                        // widest conv output (per-sample partial sums)
+    int max_bwd_m = 0;                       // widest data-gradient launch (zero bias row)
 };
 
 inline int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
@@ -170,10 +193,11 @@ inline int check_cfg(const dad_cfg* cfg) {
 struct Allocator {
     std::vector<Buf>& bufs;
     std::vector<bool> in_use;
-    explicit Allocator(std::vector<Buf>& b) : bufs(b) {}
+    bool retain;                     // training plan: a buffer is never handed out twice
+    explicit Allocator(std::vector<Buf>& b, bool keep = false) : bufs(b), retain(keep) {}
     int get(long per_sample) {
         int best = -1;
-        for (size_t i = 0; i < bufs.size(); ++i)
+        for (size_t i = 0; i < bufs.size() && !retain; ++i)
             if (!in_use[i] && bufs[i].per_sample >= per_sample &&
                 (best < 0 || bufs[i].per_sample < bufs[best].per_sample))
                 best = (int)i;
@@ -201,7 +225,8 @@ inline void expect(HostModel* m, const std::string& key, std::vector<int64_t> sh
 //         granules, and for the strided / transposed convs (no general staging path) whole
 //         64-channel chunks
 inline void decide_kernel_families(HostModel* m) {
-    for (ConvOp& op : m->plan.convs) {
+    for (Plan* plan : {&m->plan, &m->tplan})
+    for (ConvOp& op : plan->convs) {
         const int cin_all = op.cin0 + op.cin1;
         op.bdir = op.kc == 8 && op.kind == CONV_K5 &&
                   (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
@@ -215,12 +240,10 @@ inline void decide_kernel_families(HostModel* m) {
 
 // Emits the launch plan of TemporalUnet.forward (temporal_unet.py:199-241) including the
 // reference's always-upsample decoder and unused level-0 skip.
-inline int build_plan(HostModel* m) {
+inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
     const dad_cfg& c = m->cfg;
-    Plan& P = m->plan;
     P = Plan();
-    m->expected.clear();
-    Allocator A(P.bufs);
+    Allocator A(P.bufs, retain);
     const int k = c.kernel_size;
     const int tdm = c.time_dim;
     int temb_off = 0;
@@ -255,6 +278,7 @@ inline int build_plan(HostModel* m) {
         if (!norm.empty()) {
             expect(m, norm + ".weight", {cout});
             expect(m, norm + ".bias", {cout});
+            if (retain) { op.pre = A.get((long)cout * op.Lout); op.stats = A.get(16); }
         }
         P.convs.push_back(op);
     };
@@ -364,8 +388,95 @@ inline int build_plan(HostModel* m) {
         off += (b.per_sample + 3) / 4 * 4;
     }
     P.floats_per_sample = off;
-    decide_kernel_families(m);
     return DAD_OK;
+}
+// ------------------------------------------------------------------------- backward plan
+// The data gradient of every conv is itself a conv on the forward kernels, with its own weight image:
+//   Conv1d k (stride 1)          dX[ci,i] = sum_co sum_k' W[co,ci,K-1-k'] dY[co, i - K/2 + k']     same kind, transposed + flipped
+//   Downsample1d (k3, s2, p1)    dX[ci, 2j-1+k] += W[co,ci,k] dY[co,j]   = a ConvTranspose1d(k4,s2,p1) whose 4th tap is zero
+//   Upsample1d (convT k4,s2,p1)  dX[ci,i] = sum_co sum_kk Wt[ci,co,kk] dY[co, 2i-1+kk]            = a 5-tap stride-2 conv (pad 2) whose first tap is zero
+// (/root/reference/m_diffuser/models/temporal_unet.py:35-76; autograd's conv backward, restated.)
+inline int round_up(int v, int to) { return (v + to - 1) / to * to; }
+inline ConvOp make_bwd_op(const ConvOp& f, const char* tag, ConvKind kind, int taps, int stride, int cin, int c_n,
+                          int Lin, int Lout) {
+    ConvOp b;
+    b.name = f.name + tag;
+    b.kind = kind; b.taps = taps; b.stride = stride;
+    b.cin0 = cin; b.cin1 = 0;
+    b.kc = 16;
+    b.cin_pad = round_up(cin, kind == CONV_1X1 ? 128 : 64);
+    b.cout = round_up(c_n, 32);
+    b.M = kind == CONV_UP ? 2 * b.cout : b.cout;
+    b.Lin = Lin; b.Lout = Lout;
+    b.src0 = b.src1 = b.dst = b.res = -1;
+    b.temb_off = -1;
+    b.flops_per_sample = 2.0 * b.cout * cin * (kind == CONV_UP ? 4 : taps) * Lout;
+    return b;
+}
+inline int build_backward_plan(HostModel* m) {
+    const std::vector<ConvOp>& convs = m->tplan.convs;
+    m->bconvs.assign(convs.size(), HostModel::BwdConv());
+    m->grad_slots.clear(); m->grad_at.clear(); m->grad_numel = 0;
+    m->max_cout = m->cfg.dim; m->max_bwd_m = m->cfg.dim;
+    auto slot = [&](const std::string& key, long numel) {
+        m->grad_slots.push_back({key, m->grad_numel, numel});
+        m->grad_at[key] = m->grad_numel;
+        m->grad_numel += (numel + 3) / 4 * 4;
+    };
+    for (size_t i = 0; i < convs.size(); ++i) {
+        const ConvOp& f = convs[i];
+        HostModel::BwdConv& b = m->bconvs[i];
+        const int cin = f.cin0 + f.cin1;
+        switch (f.kind) {
+            case CONV_K5: case CONV_1X1:
+                b.n = f.cin1 > 0 ? 2 : 1;
+                for (int s = 0; s < b.n; ++s) {
+                    b.c_lo[s] = s == 0 ? 0 : f.cin0;
+                    b.c_n[s] = s == 0 ? f.cin0 : f.cin1;
+                    b.op[s] = make_bwd_op(f, s == 0 ? ".dgrad0" : ".dgrad1", f.kind, f.taps, 1, f.cout, b.c_n[s], f.Lin, f.Lin);
+                }
+                slot(f.name + ".weight", (long)f.cout * cin * f.taps);
+                break;
+            case CONV_DOWN:
+                b.n = 1; b.c_lo[0] = 0; b.c_n[0] = cin;
+                b.op[0] = make_bwd_op(f, ".dgrad0", CONV_UP, 2, 1, f.cout, cin, f.Lout, f.Lout);
+                slot(f.name + ".weight", (long)f.cout * cin * 3);
+                break;
+            case CONV_UP:
+                b.n = 1; b.c_lo[0] = 0; b.c_n[0] = cin;
+                b.op[0] = make_bwd_op(f, ".dgrad0", CONV_DOWN, 5, 2, f.cout, cin, 2 * f.Lin, f.Lin);
+                slot(f.name + ".weight", (long)cin * f.cout * 4);
+                break;
+        }
+        slot(f.name + ".bias", f.cout);
+        if (!f.norm.empty()) { slot(f.norm + ".weight", f.cout); slot(f.norm + ".bias", f.cout); }
+        m->max_cout = std::max(m->max_cout, f.cout);
+        for (int s = 0; s < b.n; ++s) m->max_bwd_m = std::max(m->max_bwd_m, b.op[s].M);
+    }
+    {   // final_conv[1]: 1x1, dim -> transition_dim; its data gradient is a 1x1 conv transition_dim -> dim
+        ConvOp f;
+        f.name = "final_conv.1";
+        m->bfinal = make_bwd_op(f, ".dgrad0", CONV_1X1, 1, 1, m->cfg.transition_dim, m->cfg.dim, m->cfg.horizon, m->cfg.horizon);
+        slot("final_conv.1.weight", (long)m->cfg.transition_dim * m->cfg.dim);
+        slot("final_conv.1.bias", m->cfg.transition_dim);
+    }
+    return DAD_OK;
+}
+// Why a model cannot be trained on this engine, or nullptr.
+inline const char* training_refusal(const HostModel& m) {
+    if (m.precision != DAD_PREC_FP32) return "the backward pass exists for the fp32 arithmetic only";
+    for (const ConvOp& op : m.tplan.convs)
+        if (op.cat0 >= 0) return "identity residual over a channel concat (shrinking dim_mults) has no backward kernel";
+    return nullptr;
+}
+
+inline int build_plan(HostModel* m) {
+    m->expected.clear();
+    int rc = build_plan_into(m, m->plan, false);
+    if (rc == DAD_OK) rc = build_plan_into(m, m->tplan, true);
+    if (rc == DAD_OK) decide_kernel_families(m);
+    if (rc == DAD_OK) rc = build_backward_plan(m);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------ packing
@@ -480,6 +591,59 @@ inline int pack_op(HostModel* m, ConvOp& op, PackedOp& out) {
     }
     out.bias = b->data;
     if (op.kind == CONV_UP) out.bias.insert(out.bias.end(), b->data.begin(), b->data.end());
+    return DAD_OK;
+}
+
+// Weight image of data-gradient launch `s` of forward conv `f` (see build_backward_plan).
+inline int pack_bwd_op(HostModel* m, const ConvOp& f, const HostModel::BwdConv& b, int s, std::vector<float>& out) {
+    auto it = m->raw.find(f.name + ".weight");
+    if (it == m->raw.end()) return fail(DAD_E_KEY, "missing key '%s.weight'", f.name.c_str());
+    const HostTensor& w = it->second;
+    const ConvOp& op = b.op[s];
+    const int cin = f.cin0 + f.cin1;
+    HostTensor t;
+    if (f.kind == CONV_K5 || f.kind == CONV_1X1) {
+        const int K = f.taps;
+        t.shape = {op.cout, f.cout, K};
+        t.data.assign((size_t)op.cout * f.cout * K, 0.0f);
+        for (int mm = 0; mm < b.c_n[s]; ++mm)
+            for (int co = 0; co < f.cout; ++co)
+                for (int k = 0; k < K; ++k)
+                    t.data[((size_t)mm * f.cout + co) * K + k] = w.data[((size_t)co * cin + b.c_lo[s] + mm) * K + (K - 1 - k)];
+        out.assign((size_t)op.cin_pad * K * op.M, 0.0f);
+        pack_conv_into(out, t, K, 0, 16);
+    } else if (f.kind == CONV_DOWN) {            // -> transposed conv (in = co, out = ci, 4 taps; tap 3 zero)
+        t.shape = {f.cout, cin, 4};
+        t.data.assign((size_t)f.cout * cin * 4, 0.0f);
+        for (int co = 0; co < f.cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int k = 0; k < 3; ++k)
+                    t.data[((size_t)co * cin + ci) * 4 + k] = w.data[((size_t)co * cin + ci) * 3 + k];
+        out = pack_convT(t, op.cin_pad, 16);
+    } else {                                     // CONV_UP -> 5-tap stride-2 conv (out = ci, in = co; tap 0 zero)
+        t.shape = {cin, f.cout, 5};
+        t.data.assign((size_t)cin * f.cout * 5, 0.0f);
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < f.cout; ++co)
+                for (int kk = 0; kk < 4; ++kk)
+                    t.data[((size_t)ci * f.cout + co) * 5 + kk + 1] = w.data[((size_t)ci * f.cout + co) * 4 + kk];
+        out.assign((size_t)op.cin_pad * 5 * op.M, 0.0f);
+        pack_conv_into(out, t, 5, 0, 16);
+    }
+    return DAD_OK;
+}
+inline int pack_bwd_final(HostModel* m, std::vector<float>& out) {
+    auto it = m->raw.find("final_conv.1.weight");
+    if (it == m->raw.end()) return fail(DAD_E_KEY, "missing key 'final_conv.1.weight'");
+    const HostTensor& w = it->second;            // (td, dim, 1)
+    const int td = m->cfg.transition_dim, dim = m->cfg.dim;
+    HostTensor t;
+    t.shape = {dim, td, 1};
+    t.data.assign((size_t)dim * td, 0.0f);
+    for (int j = 0; j < td; ++j)
+        for (int c = 0; c < dim; ++c) t.data[(size_t)c * td + j] = w.data[(size_t)j * dim + c];
+    out.assign((size_t)m->bfinal.cin_pad * m->bfinal.M, 0.0f);
+    pack_conv_into(out, t, 1, 0, 16);
     return DAD_OK;
 }
 
@@ -882,7 +1046,9 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         if (o.launched && o.wide && (long)batch * c.horizon > m.ccw_max_rows) return refuse(P, "wide layers and more than ccw_max_rows rows");
     {   // final_cc_kernel normalises a pair in one wave's registers
         const ConvOp& f = convs[P.final_producer];
-        if ((long)(f.cout / 8) * f.Lout > 1024 || P.ops[P.final_producer].kslices > kCcMaxSlabs) return refuse(P, "final conv: GroupNorm pair above 1024 elements");
+        if ((long)(f.cout / 8) * f.Lout > 1024) return refuse(P, "final conv: GroupNorm pair above 1024 elements");
+        // (final_cc_kernel finishes its input with cc_build_input<false>: one round of CC_MAX_SLABS = 8 slabs)
+        if (P.ops[P.final_producer].kslices > 8) return refuse(P, "final conv: more than 8 partial slabs");
     }
     P.slab_floats = off;
     P.ok = true;
@@ -915,6 +1081,12 @@ inline size_t arena_bytes_needed(const HostModel& m) {
     add(T * std::max(1, m.plan.temb_width));
     add((size_t)4 * c.time_dim * c.dim); add(4 * c.time_dim);
     add((size_t)c.time_dim * 4 * c.time_dim); add(c.time_dim);
+    if (m.training) {
+        for (const HostModel::BwdConv& b : m.bconvs)
+            for (int s = 0; s < b.n; ++s) add((size_t)b.op[s].cin_pad * b.op[s].wtaps() * b.op[s].M);
+        add((size_t)m.bfinal.cin_pad * m.bfinal.M);
+        add((size_t)std::max(m.max_bwd_m, 2 * m.max_cout) + 64);
+    }
     return floats * sizeof(float) + allocs * 256 + kMaxSplitTiles * sizeof(unsigned) + (1 << 16);
 }
 

@@ -136,6 +136,15 @@ class GuidedPolicy(nn.Module):
             if philox:
                 eng.sample_loop(x, n_steps, seed=diff.seed, row_offset=row_offset, cond0=c0,
                                 projection=projector, proj_alphas=alphas, use_graph=graph)
+            elif diff.noise_stack_bytes(shape, n_steps) > diff.max_noise_stack_bytes:
+                # the whole z stack would not be O(1) in T (1.1 GB for Door at B=128, T=1000): draw z
+                # step by step instead — the same torch.randn calls in the same order, one engine
+                # step per iteration
+                for i in reversed(range(n_steps)):
+                    eng.denoise_step(x, i, noise=torch.randn(shape, device=device), cond0=c0)
+                    if projector is not None:
+                        projector.apply(x, alphas[i])
+                return x.clone() if graph else x
             else:
                 stack = eng.persistent("z", (n_steps,) + shape) if graph else \
                     torch.empty((n_steps,) + shape, device=device)

@@ -111,6 +111,16 @@ class GaussianDiffusion(nn.Module):
         self.sampler_rng = "torch"
         self.seed = 0
         self.use_graph = False
+        # "torch" RNG: the fused loop takes the whole z stack (T, B, H, td) up to this many bytes;
+        # beyond it z is drawn step by step (same draws, same order, O(1) memory in T)
+        self.max_noise_stack_bytes = 256 << 20
+
+    @staticmethod
+    def noise_stack_bytes(shape, n_steps: int) -> int:
+        n = 4 * int(n_steps)
+        for d in shape:
+            n *= int(d)
+        return n
 
     # ------------------------------------------------------------------ engine access
     def _engine(self, device: torch.device):
@@ -191,6 +201,11 @@ class GaussianDiffusion(nn.Module):
                             use_graph=self.use_graph)
             return x.clone() if self.use_graph else x
         x = torch.randn(shape, device=device)
+        if self.noise_stack_bytes(shape, n_steps) > self.max_noise_stack_bytes:
+            # O(1) in T: z drawn per step with the reference's own call order (diffusion.py:218)
+            for i in reversed(range(n_steps)):
+                eng.denoise_step(x, i, noise=torch.randn(tuple(shape), device=device))
+            return x
         if self.use_graph:
             x = eng.persistent("x", shape).copy_(x)
         stack = eng.persistent("z", (n_steps,) + tuple(shape)) if self.use_graph else \

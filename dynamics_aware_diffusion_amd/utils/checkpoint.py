@@ -64,9 +64,15 @@ def infer_architecture(state: Mapping[str, torch.Tensor]) -> Dict[str, Any]:
         raise KeyError("missing key 'time_mlp.1.weight' / 'time_mlp.3.weight'")
     dim = int(w["time_mlp.1.weight"].shape[1])                 # SinusoidalPosEmb(dim) feeds Linear(dim, 4*time_dim)
     time_dim = int(w["time_mlp.3.weight"].shape[0])
-    if channels[0] != dim or any(c % dim for c in channels):
-        raise ValueError(f"level widths {channels} are not multiples of dim={dim} starting at dim "
+    if any(c % dim for c in channels):
+        raise ValueError(f"level widths {channels} are not multiples of dim={dim} "
                          "(the reference builds dims = [transition_dim, dim*m for m in dim_mults])")
+    if channels[0] != dim:
+        # constructible in the reference (dims = dim * m), but its forward cannot run: final_conv is
+        # Conv1dBlock(dim, dim) on a decoder that ends with dim * dim_mults[0] channels
+        # (/root/reference/m_diffuser/models/temporal_unet.py:193-197)
+        raise ValueError(f"dim_mults[0] = {channels[0] // dim}: the reference's final_conv takes dim={dim} "
+                         f"channels, the decoder of this checkpoint ends with {channels[0]}")
     return {
         "transition_dim": int(first.shape[1]),
         "kernel_size": int(first.shape[2]),
@@ -81,16 +87,21 @@ def load_checkpoint(checkpoint: Union[str, os.PathLike, Mapping[str, Any]],
                     device: Union[str, torch.device] = "cuda", use_ema: bool = False, *,
                     horizon: Optional[int] = None, observation_dim: Optional[int] = None,
                     action_dim: Optional[int] = None, beta_schedule: Optional[str] = None,
-                    precision: Optional[str] = None, strict: bool = True) -> GaussianDiffusion:
+                    precision: Optional[str] = None, strict: bool = True,
+                    weights_only: bool = True) -> GaussianDiffusion:
     """Build the sampler for a reference checkpoint and load its weights.
 
     ``checkpoint``: a path (``torch.load``-ed on the CPU) or the dict itself.  ``use_ema`` picks
     ``ema_state_dict`` instead of ``model_state_dict``.  ``horizon`` / ``observation_dim`` /
     ``action_dim`` / ``beta_schedule`` override the checkpoint's ``config`` (needed for old
     checkpoints saved without one).  Returns the model in eval mode on ``device``.
+    ``weights_only`` (default True) refuses to unpickle arbitrary objects: the dict the reference's
+    trainer writes (tensors, numbers, strings; utils/training.py:193-211) loads under it; pass
+    ``weights_only=False`` for a trusted file that holds anything else (what
+    scripts/evaluate.py:140 does unconditionally).
     """
     if not isinstance(checkpoint, Mapping):
-        checkpoint = torch.load(os.fspath(checkpoint), map_location="cpu", weights_only=False)
+        checkpoint = torch.load(os.fspath(checkpoint), map_location="cpu", weights_only=bool(weights_only))
     which = "ema_state_dict" if use_ema else "model_state_dict"
     if which not in checkpoint:
         have = sorted(k for k in checkpoint if k.endswith("state_dict"))

@@ -18,6 +18,10 @@
  *    the dad_model; the only statics are the immutable kernel table and a mutex-guarded set of
  *    devices whose kernels had their LDS limit raised.  One dad_model per device; calls on
  *    different models may run on different threads (thread-compatible: one thread per model).
+ *  - ONE STREAM PER MODEL AT A TIME: the split-K arrival tickets, the Philox key cell and the
+ *    persistent-step flags are owned by the dad_model, so two calls on the same model must not be in
+ *    flight on different streams concurrently (enqueue them on one stream, or synchronise between
+ *    streams; concurrent loops need one dad_model each, as bench.py --inflight builds them).
  */
 #ifndef DAD_H
 #define DAD_H
