@@ -83,6 +83,16 @@ ABI = {
     "dad_debug_mish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dad_debug_small_batch_plan": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                              C.POINTER(C.c_int32)]),
+    "dad_model_set_training": (C.c_int, [C.c_void_p, C.c_int32]),
+    "dad_train_grad_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "dad_train_grad_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64)]),
+    "dad_train_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_size_t)]),
+    "dad_unet_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dad_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dad_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_double)]),
@@ -160,7 +170,7 @@ class HipEngine:
     def __init__(self, *, transition_dim: int, dim: int, channels: Sequence[int], horizon: int,
                  n_timesteps: int, time_dim: Optional[int] = None, kernel_size: int = 5,
                  predict_epsilon: bool = True, clip_denoised: bool = True,
-                 device: torch.device | str = "cuda", precision: str = "fp32"):
+                 device: torch.device | str = "cuda", precision: str = "fp32", training: bool = False):
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
         self.precision = precision
@@ -188,6 +198,9 @@ class HipEngine:
         _check(self.lib, self.lib.dad_model_create(C.byref(cfg), C.byref(handle)))
         self._h = handle
         _check(self.lib, self.lib.dad_model_set_precision(self._h, PRECISIONS[precision]))
+        self.training = bool(training)
+        if self.training:
+            _check(self.lib, self.lib.dad_model_set_training(self._h, 1))
         self._ws: Dict[int, torch.Tensor] = {}
         self._pinned: Dict[tuple, torch.Tensor] = {}
         self.ready = False
@@ -352,6 +365,55 @@ class HipEngine:
             _check(self.lib, self.lib.dad_fill_normal(
                 x.data_ptr(), B, x.numel() // B, int(seed), int(row_offset), int(draw),
                 self._stream()))
+
+    # ------------------------------------------------------------------ training
+    def grad_layout(self):
+        """[(reference key without 'model.', offset in floats, numel)] of the flat gradient buffer and
+        its total length."""
+        n, total = C.c_int32(), C.c_int64()
+        _check(self.lib, self.lib.dad_train_grad_count(self._h, C.byref(n), C.byref(total)))
+        out = []
+        for i in range(n.value):
+            key, off, numel = C.c_char_p(), C.c_int64(), C.c_int64()
+            _check(self.lib, self.lib.dad_train_grad_info(self._h, i, C.byref(key), C.byref(off), C.byref(numel)))
+            out.append((key.value.decode(), off.value, numel.value))
+        return out, total.value
+
+    def train_forward(self, x: torch.Tensor, temb_rows: torch.Tensor):
+        """eps_theta(x) with per-row time projections ``temb_rows`` (B, temb_width), keeping every
+        activation: returns (out, saved) — ``saved`` goes to :meth:`train_backward`."""
+        B = self._traj(x)
+        _require_device(temb_rows, "temb_rows")
+        if temb_rows.dim() != 2 or temb_rows.shape[0] != B:
+            raise RuntimeError(f"temb_rows must be (B, temb_width), got {tuple(temb_rows.shape)}")
+        sv, sc = C.c_size_t(), C.c_size_t()
+        _check(self.lib, self.lib.dad_train_workspace_bytes(self._h, B, C.byref(sv), C.byref(sc)))
+        saved = torch.empty(max(sv.value, 4) // 4 + 4, dtype=torch.float32, device=self.device)
+        rows = torch.arange(B, dtype=torch.int32, device=self.device)
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_unet_forward_train(
+                self._h, x.data_ptr(), rows.data_ptr(), temb_rows.data_ptr(), out.data_ptr(), B,
+                saved.data_ptr(), saved.numel() * 4, self._stream()))
+        return out, saved
+
+    def train_backward(self, x: torch.Tensor, d_out: torch.Tensor, saved: torch.Tensor, temb_width: int):
+        """(d_x, d_temb_rows, flat gradient buffer) for one batch (see dad_unet_backward)."""
+        B = self._traj(x)
+        if self._traj(d_out, "d_out") != B:
+            raise RuntimeError("d_out batch mismatch")
+        sv, sc = C.c_size_t(), C.c_size_t()
+        _check(self.lib, self.lib.dad_train_workspace_bytes(self._h, B, C.byref(sv), C.byref(sc)))
+        scratch = torch.empty(max(sc.value, 4) // 4 + 4, dtype=torch.float32, device=self.device)
+        _, total = self.grad_layout()
+        grads = torch.empty(max(total, 4), dtype=torch.float32, device=self.device)
+        d_x = torch.empty_like(x)
+        d_temb = torch.empty(B, temb_width, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_unet_backward(
+                self._h, x.data_ptr(), d_out.data_ptr(), d_x.data_ptr(), d_temb.data_ptr(), grads.data_ptr(), B,
+                saved.data_ptr(), saved.numel() * 4, scratch.data_ptr(), scratch.numel() * 4, self._stream()))
+        return d_x, d_temb, grads
 
     # ------------------------------------------------------------------ test / tuning hooks
     def debug_set_tile(self, cfg: int) -> None:

@@ -1,11 +1,12 @@
 """Loss functions — API mirror of ``m_diffuser.losses``
-(/root/reference/m_diffuser/losses/__init__.py:13-236), FORWARD ONLY.
+(/root/reference/m_diffuser/losses/__init__.py:13-236).
 
 ``DiffusionLoss`` evaluates ``GaussianDiffusion.loss`` (the denoiser runs on the HIP engine with a
-per-row time embedding); ``ProjectionLoss`` measures the dynamics violation ``mean((v - vP)^2)``
-in physical units with the projection kernel of the sampler; ``ComposedLoss`` adds weighted terms.
-None of them builds an autograd graph: the engine has no backward pass, so these serve validation
-and monitoring, not optimisation.
+per-row time embedding; differentiable through the engine's explicit backward pass);
+``ProjectionLoss`` measures the dynamics violation ``mean((v - vP)^2)`` of the DATA batch in physical
+units with the projection kernel of the sampler — as in the reference it depends on no parameter, so
+it contributes a value and no gradient; ``ComposedLoss`` adds weighted terms, and
+``ComposedLoss(...)(batch)[0].backward()`` is the reference's composed training step.
 """
 from __future__ import annotations
 

@@ -6,7 +6,7 @@ Schedules are computed with the same fp32 torch ops, in the same order, as the r
 reference checkpoint's buffers load unchanged.  ``p_mean_variance`` / ``p_sample`` /
 ``p_sample_loop`` run on the HIP engine; the per-step tail (x0 prediction, clamp, posterior
 mean, noise, inpainting) is one fused kernel behind ``dad_denoise_step``.  ``loss`` evaluates the
-training objective forward-only on the same kernels.
+training objective on the same kernels and is differentiable (explicit backward pass of the engine).
 """
 from __future__ import annotations
 
@@ -216,16 +216,17 @@ class GaussianDiffusion(nn.Module):
         return x.clone() if self.use_graph else x
 
     # ------------------------------------------------------------------ training objective
-    @torch.no_grad()
     def loss(self, x_start: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """The diffusion training objective, FORWARD ONLY (diffusion.py:253-290): t ~ randint per
-        trajectory, noise ~ randn, x_t = q_sample, denoiser on the HIP engine (per-row time
-        embedding), elementwise L1 / L2 against the noise (or x_0), optional weights, mean.
+        """The diffusion training objective (diffusion.py:253-290): t ~ randint per trajectory,
+        noise ~ randn, x_t = q_sample, denoiser on the HIP engine (per-row time embedding),
+        elementwise L1 / L2 against the noise (or x_0), optional weights, mean.
 
         Same random draws in the same order as the reference (``torch.randint`` then
-        ``torch.randn_like`` on ``x_start``'s device).  The result carries no autograd graph — the
-        engine has no backward pass — so this evaluates a validation /
-        monitoring loss; calling ``.backward()`` on it raises as for any graph-less tensor."""
+        ``torch.randn_like`` on ``x_start``'s device).  With gradients enabled the result carries an
+        autograd graph whose denoiser node is the engine's explicit backward pass
+        (``dad_unet_backward``): ``loss.backward()`` fills ``.grad`` of every parameter, as the
+        reference's training step expects (utils/training.py:152-156).  Under ``torch.no_grad()`` it
+        is the forward-only validation loss."""
         batch = x_start.shape[0]
         self._engine(x_start.device)              # bind schedule / options before the model call
         t = torch.randint(0, self.n_timesteps, (batch,), device=x_start.device).long()

@@ -60,8 +60,14 @@ class TemporalUnet(nn.Module):
     ``x`` (batch, horizon, transition_dim) and ``time`` (batch,) and returns a tensor like
     ``x``.  Every sampling call site passes one shared timestep (diffusion.py:248;
     guides/policies.py:146) — the fast path; rows with different timesteps, as the training
-    objective draws them (diffusion.py:265), take the per-row time-embedding lookup.  Forward
-    only: the engine has no backward pass.
+    objective draws them (diffusion.py:265), take the per-row time-embedding lookup.
+
+    Autograd: like the reference's module, a call made with gradients enabled and a parameter (or
+    ``x``) that requires grad returns a tensor with a graph — ``loss.backward()`` then fills ``.grad``
+    of every parameter (training step of utils/training.py:144-156).  That call runs the training
+    forward of the engine (every activation kept) and the explicit backward pass of
+    ``dad_unet_backward``; the small time MLPs are evaluated with torch ops so that autograd carries
+    them.  Under ``torch.no_grad()`` (every sampling entry point) nothing of this is touched.
     """
 
     default_precision = "fp32"      # what new instances start with (see ``precision`` below)
@@ -114,7 +120,7 @@ class TemporalUnet(nn.Module):
             sched = tuple((k, v.data_ptr(), v._version) for k, v in sorted(self._schedule.items()))
         return (horizon, str(device), opts, params, sched, self.precision, bool(self.small_batch_kernels))
 
-    def engine(self, horizon: int, device: torch.device) -> HipEngine:
+    def engine(self, horizon: int, device: torch.device, training: bool = False) -> HipEngine:
         """Return the engine for (horizon, device), (re)building it if weights, schedule or
         options changed since the last call."""
         device = torch.device(device)
@@ -123,7 +129,7 @@ class TemporalUnet(nn.Module):
                 "TemporalUnet runs on the HIP engine only: move the model and its inputs to a "
                 f"ROCm device (got {device}); there is no CPU fallback")
         sig = self._signature(horizon, device)
-        if self._engine is not None and sig == self._engine_sig:
+        if self._engine is not None and sig == self._engine_sig and (self._engine.training or not training):
             return self._engine
         opts = self._diffusion_opts
         T = opts["n_timesteps"]
@@ -131,7 +137,7 @@ class TemporalUnet(nn.Module):
                         horizon=horizon, n_timesteps=T, time_dim=self.time_dim,
                         kernel_size=self.kernel_size, predict_epsilon=opts["predict_epsilon"],
                         clip_denoised=opts["clip_denoised"], device=device,
-                        precision=self.precision)
+                        precision=self.precision, training=training)
         if self._schedule is not None:
             sched = self._schedule
         else:
@@ -156,8 +162,51 @@ class TemporalUnet(nn.Module):
                 "p_sample_loop / sample_loop); got timesteps in [%d, %d]" % (lo, hi))
         return lo
 
-    @torch.no_grad()
+    # ------------------------------------------------------------------ differentiable forward
+    def _block_order(self):
+        """ResidualTemporalBlock prefixes in launch order — the order in which the engine lays their
+        time projections side by side (csrc/host_plan.hpp build_plan; temporal_unet.py:199-233)."""
+        n = len(self.dim_mults)
+        order = []
+        for i in range(n):
+            order += [f"downs.{i}.0", f"downs.{i}.1"]
+        order += ["mid_block1", "mid_block2"]
+        for j in range(n - 1):
+            order += [f"ups.{j}.0", f"ups.{j}.1"]
+        return order
+
+    def _time_projections(self, time: torch.Tensor) -> torch.Tensor:
+        """(B, sum C_out) = every block's Linear(Mish(time_mlp(SinusoidalPosEmb(t)))) side by side, with
+        torch ops (temporal_unet.py:19-32,97-100,155-160): autograd differentiates these."""
+        F = torch.nn.functional
+        p = dict(self.named_parameters())
+        half = self.dim // 2
+        scale = math.log(10000) / (half - 1)
+        freqs = torch.exp(torch.arange(half, device=time.device) * -scale)
+        arg = time[:, None] * freqs[None, :]
+        emb = torch.cat((arg.sin(), arg.cos()), dim=-1)
+        temb = F.linear(F.mish(F.linear(emb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])),
+                        p["time_mlp.3.weight"], p["time_mlp.3.bias"])
+        act = F.mish(temb)
+        return torch.cat([F.linear(act, p[b + ".time_mlp.1.weight"], p[b + ".time_mlp.1.bias"])
+                          for b in self._block_order()], dim=1).contiguous()
+
+    def _forward_autograd(self, x: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
+        eng = self.engine(int(x.shape[1]), x.device, training=True)
+        layout, _ = eng.grad_layout()
+        params = dict(self.named_parameters())
+        rows = self._time_projections(time.reshape(-1).to(x.device))
+        return _UnetFunction.apply(eng, layout, x.contiguous().float(), rows, *[params[k] for k, _, _ in layout])
+
     def forward(self, x: torch.Tensor, time: Union[int, torch.Tensor]) -> torch.Tensor:
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if isinstance(time, int):
+                time = torch.full((x.shape[0],), time, device=x.device, dtype=torch.long)
+            return self._forward_autograd(x, time)        # (any t: the sinusoid is evaluated, not looked up)
+        with torch.no_grad():
+            return self._forward_inference(x, time)
+
+    def _forward_inference(self, x: torch.Tensor, time: Union[int, torch.Tensor]) -> torch.Tensor:
         if isinstance(time, int):
             lo = hi = time
         else:
@@ -172,3 +221,27 @@ class TemporalUnet(nn.Module):
         if lo == hi:
             return eng.unet_forward(x.contiguous().float(), lo)
         return eng.unet_forward_rows(x.contiguous().float(), time.reshape(-1))
+
+
+class _UnetFunction(torch.autograd.Function):
+    """eps_theta(x) on the HIP engine with an explicit backward pass (include/dad.h, training side).
+    Inputs: the trajectory, the per-row time projections, then every conv / GroupNorm parameter in the
+    order of ``HipEngine.grad_layout()`` (their VALUES live packed inside the engine; they are inputs
+    here so that autograd routes their gradients)."""
+
+    @staticmethod
+    def forward(ctx, eng, layout, x, rows, *params):
+        out, saved = eng.train_forward(x, rows.detach().contiguous().float())
+        ctx.eng, ctx.layout, ctx.saved = eng, layout, saved
+        ctx.temb_width = int(rows.shape[1])
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        d_x, d_rows, flat = ctx.eng.train_backward(x, d_out.contiguous().float(), ctx.saved, ctx.temb_width)
+        grads = [flat[off:off + n].view(shape) for (_, off, n), shape in zip(ctx.layout, ctx.shapes)]
+        ctx.saved = None
+        return (None, None, d_x, d_rows, *grads)

@@ -121,9 +121,49 @@ int dad_unet_forward(dad_model* m, const float* x, int32_t t, float* out, int32_
 /* Replaces: TemporalUnet.forward(x, t) with one timestep PER ROW, as the training objective calls
  * it (GaussianDiffusion.loss, m_diffuser/models/diffusion.py:253-290: t ~ randint per trajectory).
  * t_rows: (B) int32 on the DEVICE, every entry in [0, n_timesteps) (the caller checks the range:
- * the library cannot without a device synchronisation).  Forward only — there is no backward. */
+ * the library cannot without a device synchronisation).  Inference form (time embeddings from the
+ * per-timestep tables); the differentiable form is dad_unet_forward_train below. */
 int dad_unet_forward_rows(dad_model* m, const float* x, const int32_t* t_rows, float* out, int32_t batch,
                           void* workspace, size_t workspace_bytes, dad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training side: replaces loss.backward() through TemporalUnet in the reference's training step
+ * (m_diffuser/utils/training.py:144-156; the objective is GaussianDiffusion.loss,
+ * m_diffuser/models/diffusion.py:253-290).  The reference relies on torch autograd; here the
+ * denoiser's backward pass is explicit:
+ *   - data gradients of Conv1d / ConvTranspose1d (temporal_unet.py:35-54,70) run on the forward
+ *     conv-GEMM kernels with transposed, tap-flipped weight images packed at dad_model_finalize;
+ *   - weight gradients are an MFMA GEMM over the batch rows (csrc/train_bwd.hpp, conv_wgrad);
+ *   - GroupNorm(8) + Mish backward (temporal_unet.py:71-72) is one kernel per conv, fed by the
+ *     pre-normalisation output and the (mean, rstd) pairs the training forward keeps.
+ * The time MLPs (SinusoidalPosEmb -> Linear -> Mish -> Linear and every block's Mish -> Linear,
+ * temporal_unet.py:97-100,155-160) stay with the caller: the forward takes their per-row outputs
+ * (B, temb_width) — the concatenation, in launch order, of every ResidualTemporalBlock's projection —
+ * and the backward returns the gradient with respect to them.  fp32 only; no optimiser, no EMA.
+ *
+ * dad_model_set_training(m, 1) must precede dad_model_finalize (the extra weight images are packed
+ * there).  Gradients come back in ONE flat fp32 device buffer; dad_train_grad_info enumerates
+ * (reference state_dict key without "model.", offset in floats, element count) — every tensor in the
+ * reference's own layout (Conv1d (out, in, k); ConvTranspose1d (in, out, k)).  The time-MLP tensors are
+ * not in the list. */
+int dad_model_set_training(dad_model* m, int32_t on);
+int dad_train_grad_count(const dad_model* m, int32_t* count, int64_t* total_floats);
+int dad_train_grad_info(const dad_model* m, int32_t i, const char** key, int64_t* offset, int64_t* numel);
+/* saved: every activation of one forward (nothing is overwritten before the backward pass reads it);
+ * scratch: gradient tensors and reduction slabs of one backward pass. */
+int dad_train_workspace_bytes(const dad_model* m, int32_t batch, size_t* saved_bytes, size_t* scratch_bytes);
+/* Replaces: TemporalUnet.forward(x, t) inside GaussianDiffusion.loss (diffusion.py:272) in training mode.
+ * row_index: (B) int32 device, row b of temb_rows that sample b uses (normally 0..B-1); temb_rows:
+ * (rows, temb_width) device fp32.  out = eps_theta (B, H, td); `saved` is handed to dad_unet_backward. */
+int dad_unet_forward_train(dad_model* m, const float* x, const int32_t* row_index, const float* temb_rows,
+                           float* out, int32_t batch, void* saved, size_t saved_bytes, dad_stream_t stream);
+/* Replaces: autograd's walk from d loss / d eps back through the denoiser.  d_out: (B, H, td);
+ * d_x (optional): (B, H, td) gradient w.r.t. the noisy trajectory; d_temb_rows: (B, temb_width), fully
+ * overwritten; grads: the flat buffer of dad_train_grad_count floats, fully overwritten (each call
+ * computes the gradient of ONE batch; accumulation over micro-batches is the caller's add). */
+int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d_x, float* d_temb_rows,
+                      float* grads, int32_t batch, void* saved, size_t saved_bytes, void* scratch,
+                      size_t scratch_bytes, dad_stream_t stream);
 
 /* Arguments of one reverse step beyond (x, t). All pointers may be NULL unless noted. */
 typedef struct dad_step_args {

@@ -251,6 +251,26 @@ def training_loss(w, sched: Mapping[str, Tensor], x_start: Tensor, t: Tensor, no
         return per.mean(), x_t, out
 
 
+def training_gradients(w: Mapping[str, Tensor], sched: Mapping[str, Tensor], x_start: Tensor, t: Tensor,
+                       noise: Tensor, loss_type: str = "l2", predict_epsilon: bool = True,
+                       weights: Optional[Tensor] = None) -> Tuple[Tensor, Dict[str, Tensor], Tensor]:
+    """What the reference's training step computes with ``loss.backward()`` (utils/training.py:152-156)
+    for GaussianDiffusion.loss (diffusion.py:253-290), its two random draws passed in: torch autograd
+    over this file's restatement of the forward.  Returns (loss, {key: d loss / d weight}, d loss / d x_t)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in w.items()}
+    x_t = (_at(sched["sqrt_alphas_cumprod"], t, x_start.dim()) * x_start
+           + _at(sched["sqrt_one_minus_alphas_cumprod"], t, x_start.dim()) * noise).detach().requires_grad_(True)
+    with torch.enable_grad():
+        out = unet_forward(leaves, x_t, t)
+        target = noise if predict_epsilon else x_start
+        per = (out - target) ** 2 if loss_type == "l2" else (out - target).abs()
+        if weights is not None:
+            per = per * weights
+        loss = per.mean()
+        loss.backward()
+    return loss.detach(), {k: v.grad.detach() for k, v in leaves.items()}, x_t.grad.detach()
+
+
 def cast_weights(w: Mapping[str, Tensor], dtype: torch.dtype) -> Dict[str, Tensor]:
     return {k: v.to(dtype) for k, v in w.items()}
 

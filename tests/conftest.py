@@ -30,3 +30,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _inference_by_default():
+    """Tests run under torch.no_grad() unless they open torch.enable_grad() themselves: like the
+    reference's module, TemporalUnet returns a tensor with an autograd graph (training forward +
+    explicit backward pass of the engine) whenever gradients are enabled and a parameter requires grad;
+    the parity tests of the sampling path want the inference kernels."""
+    import torch
+    with torch.no_grad():
+        yield

@@ -158,6 +158,25 @@ TRAIN_CASES = [
 ]
 
 
+# Backward pass (utils/training.py:152-156: loss.backward() through the denoiser): every parameter
+# gradient + d loss / d x_t of the reference, draws injected as above.  Large tensors are pinned by a
+# strided sample + their sum and sum of squares (the GPU test also compares EVERY element with the
+# oracle's autograd, which test_oracle_golden.py holds to these samples).
+# (case, net, T, B, loss_type, predict_epsilon, weighted)
+GRAD_CASES = [
+    ("grads_tiny", "tiny", 20, 6, "l2", True, False),
+    ("grads_tiny4", "tiny4", 20, 5, "l1", True, True),
+    ("grads_pointmaze_B9", "pointmaze", 100, 9, "l2", True, False),
+]
+GRAD_SAMPLE = 2048
+
+
+def grad_sample_index(numel: int) -> np.ndarray:
+    if numel <= 2 * GRAD_SAMPLE:
+        return np.arange(numel)
+    return np.arange(GRAD_SAMPLE) * (numel // GRAD_SAMPLE)
+
+
 def train_inputs(case: str, net: str, T: int, B: int, weighted: bool):
     """(x_start, per-row timesteps, noise, weights or None): what loss() draws, made portable."""
     _, _, td, _, _ = net_dims(net)

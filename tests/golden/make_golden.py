@@ -338,6 +338,45 @@ def gen_training():
     save("training", **out)
 
 
+def gen_grads():
+    """The reference's own backward pass (utils/training.py:152-156): GaussianDiffusion.loss arithmetic
+    (diffusion.py:253-290) on injected draws, loss.backward(), every parameter gradient and d loss / d x_t."""
+    for case, net, T, B, loss_type, pred_eps, weighted in cases.GRAD_CASES:
+        print(f"  grads {case} ...", flush=True)
+        diff = build_reference(net, T, loss_type=loss_type, predict_epsilon=pred_eps).train()
+        x0, t, noise, w = cases.train_inputs(case, net, T, B, weighted)
+        x0t, tt, nz = torch.from_numpy(x0), torch.from_numpy(t), torch.from_numpy(noise)
+        wt = None if w is None else torch.from_numpy(w)
+        # the loss exactly as diffusion.py:253-290 computes it, with x_t a leaf so that its gradient exists
+        x_t = diff.q_sample(x0t, tt, nz).detach().requires_grad_(True)
+        out = diff.model(x_t, tt)
+        per = diff.loss_fn(out, nz if pred_eps else x0t)
+        if wt is not None:
+            per = per * wt
+        loss = per.mean()
+        diff.zero_grad()
+        loss.backward()
+        # cross-check against the module's own loss() on the same draws
+        real_randint = torch.randint
+        torch.randint = lambda *a, **k: tt.clone()
+        try:
+            with injected_noise(noise[None]), torch.no_grad():
+                ref_loss = diff.loss(x0t, wt)
+        finally:
+            torch.randint = real_randint
+        assert abs(float(ref_loss) - float(loss)) <= 1e-7 * max(1.0, abs(float(loss))), (float(ref_loss), float(loss))
+        arrays = {"loss": np.float64(loss.item()), "dx": x_t.grad.numpy()}
+        for k, p in diff.model.named_parameters():
+            g = p.grad.numpy().reshape(-1)
+            idx = cases.grad_sample_index(g.size)
+            arrays["g." + k] = g[idx]
+            arrays["sum." + k] = np.float64(g.astype(np.float64).sum())
+            arrays["sq." + k] = np.float64((g.astype(np.float64) ** 2).sum())
+            arrays["max." + k] = np.float64(np.abs(g).max())
+        save(case, **arrays)
+        del diff
+
+
 class ValueNet(torch.nn.Module):
     def __init__(self, od):
         super().__init__()
@@ -458,7 +497,7 @@ SECTIONS = {
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
     "forward": gen_forward, "loops": gen_loops, "long_loops": gen_long_loops,
     "proj_loops": gen_proj_loops, "options": gen_options, "training": gen_training,
-    "guidance": gen_guidance,
+    "guidance": gen_guidance, "grads": gen_grads,
     "projection": gen_projection, "glue": gen_glue, "sysid": gen_sysid,
 }
 

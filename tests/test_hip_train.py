@@ -1,0 +1,152 @@
+"""GPU parity of the backward pass: ``loss.backward()`` through the HIP engine
+(training forward + dad_unet_backward) against the reference's own autograd — every parameter gradient
+and d loss / d x_t.
+
+Fixtures: ``grads_*.npz`` hold, per parameter, a strided sample of the reference's gradient plus its sum,
+sum of squares and max |g| (tests/golden/make_golden.py::gen_grads); the oracle's autograd over its
+restatement of the forward is pinned to the same fixtures on the CPU (test_oracle_golden.py) and gives
+the element-by-element comparison here.  Gate: |g_hip - g_ref| <= 2e-5 * max|g_ref| per tensor.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.test_hip_parity import build, dev, injected_noise  # noqa: F401  (dev: fixture)
+from tests.util import golden, max_abs, net_weights_torch
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5
+
+
+def _loss_and_backward(diff, name, net, T, B, weighted, devc):
+    x0, t, noise, wts = cases.train_inputs(name, net, T, B, weighted)
+    tt = torch.from_numpy(t).to(devc)
+    for p in diff.parameters():
+        p.grad = None
+    real_randint = torch.randint
+    torch.randint = lambda *a, **k: tt.clone()
+    try:
+        with injected_noise(noise[None], devc), torch.enable_grad():
+            loss = diff.loss(torch.from_numpy(x0).to(devc), None if wts is None else torch.from_numpy(wts).to(devc))
+            assert loss.requires_grad
+            loss.backward()
+    finally:
+        torch.randint = real_randint
+    torch.cuda.synchronize()
+    return loss
+
+
+@pytest.mark.parametrize("case", cases.GRAD_CASES, ids=lambda c: c[0])
+def test_parameter_gradients_vs_reference(case, dev):
+    from oracle import denoiser as orc
+    name, net, T, B, loss_type, pred_eps, weighted = case
+    g = golden(name)
+    diff = build(net, T, "cosine", dev, loss_type=loss_type, predict_epsilon=pred_eps)
+    loss = _loss_and_backward(diff, name, net, T, B, weighted, dev)
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * max(1.0, abs(float(g["loss"])))
+    # the oracle's autograd: every element of every tensor
+    x0, t, noise, wts = cases.train_inputs(name, net, T, B, weighted)
+    _, og, odx = orc.training_gradients(net_weights_torch(net), orc.schedule_buffers("cosine", T), torch.from_numpy(x0),
+                                        torch.from_numpy(t), torch.from_numpy(noise), loss_type, pred_eps,
+                                        None if wts is None else torch.from_numpy(wts))
+    worst, worst_key = 0.0, None
+    params = dict(diff.model.named_parameters())
+    assert set(params) == set(og)
+    for k, p in params.items():
+        assert p.grad is not None, f"no gradient reached {k}"
+        got = p.grad.detach().cpu().numpy()
+        assert np.isfinite(got).all(), k
+        scale = max(float(g["max." + k]), 1e-12)
+        flat = got.reshape(-1)
+        idx = cases.grad_sample_index(flat.size)
+        e_ref = float(np.max(np.abs(flat[idx].astype(np.float64) - g["g." + k]))) / scale      # the reference itself
+        e_orc = max_abs(got, og[k].numpy()) / scale                                            # every element
+        e_sum = abs(float(flat.astype(np.float64).sum()) - float(g["sum." + k])) / (scale * max(1.0, np.sqrt(flat.size)))
+        if max(e_ref, e_orc) > worst:
+            worst, worst_key = max(e_ref, e_orc), k
+        assert e_ref <= REL and e_orc <= REL, f"{k}: rel err vs reference {e_ref:.2e}, vs oracle {e_orc:.2e}"
+        assert e_sum <= REL, f"{k}: sum of the gradient off by {e_sum:.2e} (relative to max|g| sqrt(n))"
+    print(f"{name}: worst parameter-gradient error {worst:.2e} x max|g| ({worst_key})")
+
+
+@pytest.mark.parametrize("case", cases.GRAD_CASES[:2], ids=lambda c: c[0])
+def test_input_gradient_and_repeatability(case, dev):
+    """d loss / d x_t through a direct model call with a leaf input, per-row timesteps; a second backward
+    pass reproduces the first bit for bit (fixed-order reductions, no atomics)."""
+    name, net, T, B, loss_type, pred_eps, weighted = case
+    g = golden(name)
+    diff = build(net, T, "cosine", dev, loss_type=loss_type, predict_epsilon=pred_eps)
+    x0, t, noise, wts = cases.train_inputs(name, net, T, B, weighted)
+    x0t, tt, nz = torch.from_numpy(x0).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(noise).to(dev)
+    runs = []
+    for _ in range(2):
+        for p in diff.parameters():
+            p.grad = None
+        with torch.enable_grad():
+            x_t = diff.q_sample(x0t, tt, nz).detach().requires_grad_(True)
+            out = diff.model(x_t, tt)
+            per = diff.loss_fn(out, nz if pred_eps else x0t)
+            if wts is not None:
+                per = per * torch.from_numpy(wts).to(dev)
+            per.mean().backward()
+        torch.cuda.synchronize()
+        runs.append((x_t.grad.cpu().numpy(), {k: p.grad.cpu().numpy().copy() for k, p in diff.model.named_parameters()}))
+    scale = float(np.abs(g["dx"]).max())
+    err = max_abs(runs[0][0], g["dx"]) / scale
+    print(f"{name}: d loss / d x_t error {err:.2e} x max|g|")
+    assert err <= REL
+    assert np.array_equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
+
+
+def test_composed_loss_backward(dev):
+    """ComposedLoss([DiffusionLoss, ProjectionLoss]).backward() — the reference's composed training step
+    (losses/__init__.py:189-227, utils/training.py:130-156): the projection term depends on the data
+    only, so the parameter gradients equal the diffusion term's."""
+    from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder, double_integrator
+    from dynamics_aware_diffusion_amd.losses import ComposedLoss, DiffusionLoss, ProjectionLoss
+    import contextlib
+    import io
+    name, net, T, B, loss_type, pred_eps, weighted = cases.GRAD_CASES[0]
+    g = golden(name)
+    diff = build(net, T, "cosine", dev, loss_type=loss_type, predict_epsilon=pred_eps)
+    A, Bm = double_integrator(0.1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        P = ProjectionMatrixBuilder(A, Bm, 4, 2).get_projection_matrix(cases.H)
+        terms = ComposedLoss([DiffusionLoss(diff, 1.0),
+                              ProjectionLoss(P, cases.NormalizerStub(4, 2), state_dim=4, action_dim=2, observation_dim=4,
+                                             horizon=cases.H, weight=0.1, device=str(dev))])
+    x0, t, noise, _ = cases.train_inputs(name, net, T, B, weighted)
+    tt = torch.from_numpy(t).to(dev)
+    for p in diff.parameters():
+        p.grad = None
+    real_randint = torch.randint
+    torch.randint = lambda *a, **k: tt.clone()
+    try:
+        with injected_noise(noise[None], dev), torch.enable_grad():
+            total, parts = terms({"conditions": torch.from_numpy(x0).to(dev)})
+            total.backward()
+    finally:
+        torch.randint = real_randint
+    torch.cuda.synchronize()
+    assert abs(parts["diffusion"] - float(g["loss"])) <= 2e-6 * max(1.0, abs(float(g["loss"])))
+    assert abs(parts["total"] - (parts["diffusion"] + parts["projection"])) <= 1e-6 * max(1.0, abs(parts["total"]))
+    for k, p in diff.model.named_parameters():
+        flat = p.grad.cpu().numpy().reshape(-1)
+        idx = cases.grad_sample_index(flat.size)
+        assert float(np.max(np.abs(flat[idx] - g["g." + k]))) <= REL * max(float(g["max." + k]), 1e-12), k
+
+
+def test_training_refusals(dev):
+    """What cannot be trained is refused with a message, not run wrongly: the split-f16 arithmetic."""
+    from dynamics_aware_diffusion_amd._engine import DadError
+    diff = build("tiny", 20, "cosine", dev)
+    diff.model.precision = "f16x3"
+    try:
+        with torch.enable_grad(), pytest.raises(DadError, match="fp32"):
+            diff.model(torch.zeros(2, cases.H, 6, device=dev), torch.zeros(2, dtype=torch.long, device=dev))
+    finally:
+        diff.model.precision = "fp32"

@@ -280,3 +280,23 @@ def test_system_identification_vs_reference():
     for got, key in ((A4, "A4"), (B4, "B4"), (A6, "A6"), (B6, "B6")):
         assert got.shape == g[key].shape
         assert max_abs(got, g[key]) <= 1e-12, key
+
+
+@pytest.mark.parametrize("case", cases.GRAD_CASES, ids=lambda c: c[0])
+def test_oracle_training_gradients_vs_reference(case):
+    """The oracle's autograd over its restatement of the forward, against the reference's own
+    loss.backward() (tests/golden/make_golden.py::gen_grads): pins the element-by-element reference the
+    GPU backward pass is compared with."""
+    name, net, T, B, loss_type, pred_eps, weighted = case
+    g = golden(name)
+    x0, t, noise, wts = cases.train_inputs(name, net, T, B, weighted)
+    loss, grads, dx = od.training_gradients(
+        net_weights_torch(net), od.schedule_buffers("cosine", T), torch.from_numpy(x0), torch.from_numpy(t),
+        torch.from_numpy(noise), loss_type, pred_eps, None if wts is None else torch.from_numpy(wts))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * max(1.0, abs(float(g["loss"])))
+    assert max_abs(dx.numpy(), g["dx"]) <= 2e-6 * float(np.abs(g["dx"]).max())
+    for k, v in grads.items():
+        flat = v.numpy().reshape(-1)
+        idx = cases.grad_sample_index(flat.size)
+        scale = max(float(g["max." + k]), 1e-12)
+        assert float(np.max(np.abs(flat[idx] - g["g." + k]))) <= 2e-6 * scale, k
