@@ -417,7 +417,7 @@ class HipEngine:
 
     # ------------------------------------------------------------------ test / tuning hooks
     def debug_set_tile(self, cfg: int) -> None:
-        """Force a conv tile (0..7), -1 = heuristic, 100+cfg / 99 = same without grid split-K."""
+        """Force a conv tile (0..9), -1 = heuristic, 100+cfg / 99 = same without grid split-K."""
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.dad_debug_set_tile(self._h, int(cfg)))
 

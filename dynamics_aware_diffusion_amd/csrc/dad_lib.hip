@@ -174,6 +174,7 @@ const KernTable& kernel_table() {
         KernTable t;
         reg_tile<0>(t); reg_tile<1>(t); reg_tile<2>(t); reg_tile<3>(t);
         reg_tile<4>(t); reg_tile<5>(t); reg_tile<6>(t); reg_tile<7>(t);
+        reg_tile<8>(t); reg_tile<9>(t);
         return t;
     }();
     return table;

@@ -100,7 +100,7 @@ constexpr int kMaxSplitTiles = 4096;
 struct TileCfg { int BM, BN, SK, KC; };
 // Block tile (BM channels x BN positions), SK-way intra-block split-K, K chunk.  Every
 // configuration runs 8 waves per block except the last three.
-constexpr int kNumTiles = 8;
+constexpr int kNumTiles = 10;
 constexpr TileCfg kTiles[kNumTiles] = {
     {32, 64, 4, 32},    // 0: few output tiles -> deepest split-K
     {64, 64, 2, 32},    // 1: the workhorse at batch 256
@@ -110,6 +110,8 @@ constexpr TileCfg kTiles[kNumTiles] = {
     {32, 64, 2, 16},    // 5: 4 waves, small LDS: several independent blocks per CU
     {32, 64, 1, 16},    // 6: 2 waves
     {64, 64, 2, 16},    // 7: as 1 with the shallower K chunk (two blocks per CU fit)
+    {32, 128, 2, 32},   // 8: layers of 128 positions (horizon 128, QUICKSTART.md:82): one sample per tile
+    {64, 128, 1, 16},   // 9: the same with 64-channel tiles (GroupNorm groups of 64 channels)
 };
 
 // 1x1 convs have one (tap, group) unit per 8 channels: a deep K chunk keeps enough MFMAs between
@@ -680,6 +682,8 @@ inline int choose_tile(const HostModel& m, const ConvOp& op, int batch) {
     if (valid(1)) return 1;
     if (valid(2)) return 2;
     if (valid(4)) return 4;
+    if (valid(8)) return 8;              // 128 positions per sample
+    if (valid(9)) return 9;
     return -1;
 }
 

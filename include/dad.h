@@ -244,7 +244,7 @@ int dad_profile_enable(dad_model* m, int32_t on);
 int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops);
 
 /* Test / tuning hooks, all per model (two models in one process do not interact).
- * dad_debug_set_tile: force conv tile configuration `cfg` (0..7, see kTiles in csrc/host_plan.hpp)
+ * dad_debug_set_tile: force conv tile configuration `cfg` (0..9, see kTiles in csrc/host_plan.hpp)
  * wherever it is valid for a layer; -1 restores the heuristic; 100+cfg (99 = heuristic tile)
  * additionally disables grid-level split-K.
  * dad_debug_set_option: "fuse_residual" (the 1x1 residual conv rides in its block's first conv

@@ -88,15 +88,21 @@ NETS = {
     "pointmaze": (4, 2, 128, (1, 2, 4), 100, 0, 0.0),
     "halfcheetah": (17, 6, 256, (1, 4, 8), 1000, 0, 0.0),
     "door": (39, 28, 256, (1, 2, 4, 8), 1000, 0, 0.0),
+    # the same three architectures with non-trivial GroupNorm affine parameters (gamma = 1 + 0.25 U,
+    # beta = 0.25 U): the single-forward goldens use these, so that a gamma / beta indexing slip in the
+    # 128- and 256-channel-group tiles cannot hide behind gamma = 1, beta = 0
+    "pointmaze_j": (4, 2, 128, (1, 2, 4), 100, 8, 0.25),
+    "halfcheetah_j": (17, 6, 256, (1, 4, 8), 1000, 8, 0.25),
+    "door_j": (39, 28, 256, (1, 2, 4, 8), 1000, 8, 0.25),
 }
 
 # (case, net, B, t)  — single U-Net forward
 FORWARD_CASES = [
     ("fwd_tiny", "tiny", 3, 7),
     ("fwd_tiny4", "tiny4", 5, 13),
-    ("fwd_pointmaze", "pointmaze", 2, 63),
-    ("fwd_halfcheetah", "halfcheetah", 2, 500),
-    ("fwd_door", "door", 2, 999),
+    ("fwd_pointmaze", "pointmaze_j", 2, 63),
+    ("fwd_halfcheetah", "halfcheetah_j", 2, 500),
+    ("fwd_door", "door_j", 2, 999),
 ]
 
 # (case, net, T_train, n_sample_steps, B, conditioned, schedule)
@@ -141,6 +147,13 @@ OPTION_CASES = [
 GUIDE_CASES = [
     ("guide_tiny_w0p1", "tiny", 20, 3, 0.1),
     ("guide_tiny_w1", "tiny", 20, 3, 1.0),
+    ("guide_pointmaze_w1", "pointmaze", 100, 3, 1.0),     # BASELINE architecture, full T=100 guided loop
+]
+# Guided loops truncated to a few steps (evaluate.py:350-353 semantics) on the widest transition: the
+# guide axpy at td = 67, where the posterior kernel spreads the columns over gridDim.y.
+# (case, net, T_train, n_steps, B, guide_weight)
+GUIDE_SHORT_CASES = [
+    ("guide_door_w0p5_T4", "door_j", 1000, 4, 2, 0.5),
 ]
 VALUE_HIDDEN = 16
 

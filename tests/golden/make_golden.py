@@ -148,7 +148,7 @@ def gen_units():
 
 def gen_forward(only_small: bool = False):
     for case, net, B, t in cases.FORWARD_CASES:
-        if only_small and net in ("halfcheetah", "door"):
+        if only_small and net.startswith(("halfcheetah", "door")):
             continue
         print(f"  forward {case} ...")
         od, ad, td, dim, mults = cases.net_dims(net)
@@ -411,6 +411,28 @@ def gen_guidance():
         save(case, x_final=x.numpy(), first_step=step.numpy(), first_grad=grad.numpy())
 
 
+def gen_guidance_short():
+    """ValueGuidedPolicy (policies.py:243-271) on the Door architecture, loop truncated to a few steps."""
+    for case, net, T, n_steps, B, gw in cases.GUIDE_SHORT_CASES:
+        print(f"  guidance {case} ...", flush=True)
+        diff = build_reference(net, T)
+        diff.n_timesteps = n_steps
+        od = diff.observation_dim
+        pol = ref_pol.ValueGuidedPolicy(diff, None, ValueNet(od), guide_weight=gw)
+        noise = cases.loop_noise(case, net, n_steps, B)
+        cond = {0: torch.from_numpy(cases.loop_condition(case, net))}
+        with injected_noise(noise):
+            x = pol.sample_loop(batch_size=B, conditions=cond)
+        x0 = torch.from_numpy(noise[0]).clone()
+        x0[:, 0] = cond[0]
+        tt = torch.full((B,), n_steps - 1, dtype=torch.long)
+        xg = x0.clone().requires_grad_(True)
+        grad = torch.autograd.grad(pol.guide_fn(xg, tt).sum(), xg)[0]
+        with injected_noise(noise[1:2]):
+            step = pol.p_sample_with_guidance(x0.clone(), tt, cond)
+        save(case, x_final=x.numpy(), first_step=step.numpy(), first_grad=grad.numpy())
+
+
 def gen_projection():
     out = {}
     from oracle.projection import double_integrator
@@ -478,7 +500,7 @@ def gen_keys():
     """state_dict key -> shape of the reference GaussianDiffusion for every architecture."""
     import json
     out = {}
-    for net in ("tiny", "tiny4", "pointmaze", "halfcheetah", "door"):
+    for net in ("tiny", "tiny4", "pointmaze", "halfcheetah", "door"):        # (the *_j nets share these shapes)
         od, ad, td, dim, mults = cases.net_dims(net)
         with torch.device("meta"):
             unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults))
@@ -497,7 +519,7 @@ SECTIONS = {
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
     "forward": gen_forward, "loops": gen_loops, "long_loops": gen_long_loops,
     "proj_loops": gen_proj_loops, "options": gen_options, "training": gen_training,
-    "guidance": gen_guidance, "grads": gen_grads,
+    "guidance": gen_guidance, "guidance_short": gen_guidance_short, "grads": gen_grads,
     "projection": gen_projection, "glue": gen_glue, "sysid": gen_sysid,
 }
 

@@ -26,7 +26,7 @@ def _oracle_eps(net, x, t):
         return orc.unet_forward(net_weights_torch(net), x, torch.full((x.shape[0],), t, dtype=torch.long))
 
 
-@pytest.mark.parametrize("tile", list(range(8)))
+@pytest.mark.parametrize("tile", list(range(10)))
 def test_every_tile_variant_matches_oracle(tile, dev):
     """Force each (BM, BN, split-K, K-chunk) instantiation wherever it is valid."""
     from dynamics_aware_diffusion_amd.utils import synth
@@ -92,6 +92,59 @@ def test_wide_nets_at_a_ragged_multi_tile_batch(net, dev):
     want = _oracle_eps(net, x, t).numpy()
     got = diff.model(x.to(dev), t).cpu().numpy()
     assert max_abs(got, want) <= TOL_STEP
+
+
+@pytest.mark.parametrize("net", ["halfcheetah_j", "door_j"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_wide_nets_nontrivial_affine_through_the_batch_kernels(net, precision, dev):
+    """B = 33 with GroupNorm gamma / beta off their defaults on the 1024 / 2048-channel nets, through the
+    batch-256 kernels (<128,64>, <256,32,BDIR>, grid split-K) in both conv arithmetics: a per-channel
+    parameter indexing slip in the wide-group tiles would show here."""
+    from dynamics_aware_diffusion_amd.utils import synth
+    diff = build(net, cases.NETS[net][4], "cosine", dev)
+    diff.model.precision = precision
+    try:
+        B, t = 33, 777
+        x = torch.from_numpy(synth.normal_like(81, f"widej.{net}", (B, 32, diff.transition_dim)))
+        want = _oracle_eps(net, x, t).numpy()
+        got = diff.model(x.to(dev), t).cpu().numpy()
+    finally:
+        diff.model.precision = "fp32"
+    assert max_abs(got, want) <= TOL_STEP
+
+
+# Frozen draws of tests/fuzz_parity.py (widths >= 1024, batches 5..40, both arithmetics): the manual
+# sweep found nothing in 400+ cases; these keep a fixed sample of it inside `-m gpu`.
+# (dim, dim_mults, horizon, transition_dim, batch, precision, t)
+FROZEN_FUZZ = [
+    (128, (1, 8), 32, 11, 5, "fp32", 3), (128, (1, 8), 16, 7, 40, "f16x3", 17), (256, (1, 4), 32, 23, 9, "fp32", 0),
+    (256, (1, 4), 8, 5, 33, "f16x3", 19), (256, (1, 8), 16, 14, 6, "fp32", 11), (256, (1, 8), 32, 3, 13, "f16x3", 8),
+    (128, (1, 2, 8), 32, 9, 7, "fp32", 5), (128, (1, 4, 8), 16, 20, 21, "f16x3", 2), (256, (1, 2, 4), 32, 17, 16, "fp32", 14),
+    (256, (1, 4, 4), 16, 6, 31, "f16x3", 9), (256, (1, 4, 8), 32, 12, 8, "fp32", 1), (256, (1, 8, 4), 32, 4, 5, "f16x3", 16),
+    (128, (1, 8, 8), 32, 24, 12, "fp32", 7), (128, (1, 2, 4, 8), 32, 8, 10, "f16x3", 13), (256, (1, 2, 4, 8), 32, 19, 5, "fp32", 18),
+    (256, (1, 1, 4, 8), 32, 2, 27, "f16x3", 4), (64, (1, 4, 16), 32, 10, 36, "fp32", 6), (64, (1, 16), 16, 15, 14, "f16x3", 10),
+    (256, (1, 8, 8), 16, 21, 11, "fp32", 15), (128, (1, 8, 2), 32, 13, 24, "f16x3", 12),
+]
+
+
+@pytest.mark.parametrize("draw", FROZEN_FUZZ, ids=lambda d: "d%d_m%s_H%d_td%d_B%d_%s" % (d[0], "x".join(map(str, d[1])), d[2], d[3], d[4], d[5]))
+def test_frozen_fuzz_draws_match_oracle(draw, dev):
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    from dynamics_aware_diffusion_amd.utils import synth
+    dim, mults, H, td, B, prec, t = draw
+    tag = "frozen.%d.%s.%d.%d" % (dim, "-".join(map(str, mults)), H, td)
+    state = synth.synth_unet_state(td, dim, mults, seed=91, affine_jitter=0.3)
+    w = {k: torch.from_numpy(v) for k, v in state.items()}
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet.load_state_dict(w)
+    unet.precision = prec
+    diff = GaussianDiffusion(unet, H, td - 1, 1, n_timesteps=20).to(dev)
+    x = torch.from_numpy(synth.normal_like(92, tag, (B, H, td)))
+    with torch.no_grad():
+        want = orc.unet_forward(w, x, torch.full((B,), t, dtype=torch.long))
+    got = diff.model(x.to(dev), t)
+    torch.cuda.synchronize()
+    assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP
 
 
 @pytest.mark.parametrize("net,B", [("halfcheetah", 1), ("halfcheetah", 2), ("halfcheetah", 5), ("halfcheetah", 16),
@@ -416,7 +469,11 @@ def test_graph_replay_with_inkernel_noise(dev):
                                        # trajectory itself (nn.Identity, temporal_unet.py:92-94)
     (9, 256, (1, 8), 32, 2),           # 2048 channels at 16 positions: GroupNorm pairs of 4096 elements
                                        # (conv_ccw re-reads LDS between the passes at small batch)
-], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}")
+    (6, 128, (1, 2, 4), 128, 1),       # horizon 128 (the reference's QUICKSTART.md:82 recipe): 128-position
+    (6, 128, (1, 2, 4), 128, 9),       # tiles <32,128> on level 0, batch 1 and 9
+    (23, 256, (1, 4, 8), 128, 3),      # the same on the HalfCheetah widths (64-channel groups at L = 64: <128,64>)
+    (14, 64, (1, 2, 4, 8), 64, 5),     # horizon 64 on four levels
+], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}")
 def test_assorted_architectures_match_oracle(arch, dev):
     """Shapes outside the three BASELINE architectures, against the oracle on seeded inputs."""
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet

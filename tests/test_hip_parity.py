@@ -429,6 +429,37 @@ def test_value_guidance_vs_reference(case, dev):
     assert max_abs(x.cpu().numpy(), g["x_final"]) <= TOL_LOOP
 
 
+@pytest.mark.parametrize("case", cases.GUIDE_SHORT_CASES, ids=lambda c: c[0])
+def test_value_guidance_on_the_widest_transition_vs_reference(case, dev):
+    """The reference's ValueGuidedPolicy (guides/policies.py:243-271) on the Door architecture: the guide
+    axpy of the posterior kernel at td = 67 (columns spread over gridDim.y), GroupNorm affine parameters
+    off their defaults, loop truncated to n_steps of the T = 1000 schedule."""
+    from dynamics_aware_diffusion_amd import ValueGuidedPolicy
+    name, net, T, n_steps, B, gw = case
+    g = golden(name)
+    diff = build(net, T, "cosine", dev)
+    keep = diff.n_timesteps
+    diff.n_timesteps = n_steps
+    try:
+        pol = ValueGuidedPolicy(diff, None, _value_model(diff.observation_dim, dev), guide_weight=gw)
+        noise = cases.loop_noise(name, net, n_steps, B)
+        cond = {0: torch.from_numpy(cases.loop_condition(name, net)).to(dev)}
+        with injected_noise(noise, dev):
+            x = pol.sample_loop(batch_size=B, conditions=cond)
+        x0 = torch.from_numpy(noise[0]).to(dev)
+        x0[:, 0] = cond[0]
+        t = torch.full((B,), n_steps - 1, device=dev, dtype=torch.long)
+        grad = pol._guide_gradient(x0, t)
+        with injected_noise(noise[1:2], dev):
+            step = pol.p_sample_with_guidance(x0.clone(), t, cond)
+        torch.cuda.synchronize()
+    finally:
+        diff.n_timesteps = keep
+    assert max_abs(grad.cpu().numpy(), g["first_grad"]) <= 1e-6
+    assert max_abs(step.cpu().numpy(), g["first_step"]) <= TOL_STEP * eps_gain(diff, n_steps - 1)
+    assert max_abs(x.cpu().numpy(), g["x_final"]) <= TOL_LOOP
+
+
 def test_projection_vs_reference(dev):
     from dynamics_aware_diffusion_amd import DynamicsAwarePolicy
     from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder

@@ -53,7 +53,7 @@ def test_unit_layers(case):
     assert max_abs(y.numpy(), g[name]) <= TOL
 
 
-@pytest.mark.parametrize("case", [c for c in cases.FORWARD_CASES if c[1] in ("tiny", "tiny4", "pointmaze")],
+@pytest.mark.parametrize("case", [c for c in cases.FORWARD_CASES if c[1] in ("tiny", "tiny4", "pointmaze_j")],
                          ids=lambda c: c[0])
 def test_unet_forward(case):
     name, net, B, t = case
@@ -235,7 +235,32 @@ def test_value_guidance(case):
     t = torch.full((B,), T - 1, dtype=torch.long)
     grad = od.guide_gradient(guide_fn, x0, t)
     assert max_abs(grad.numpy(), g["first_grad"]) <= TOL
-    assert np.all(grad.numpy()[:, :, 4:] == 0)           # action channels get no gradient
+    assert np.all(grad.numpy()[:, :, cases.net_dims(net)[0]:] == 0)           # action channels get no gradient
+    with torch.no_grad():
+        step = od.denoise_step(w, sched, x0, t, noise[1], cond, grad, gw)
+    assert max_abs(step.numpy(), g["first_step"]) <= TOL
+
+
+@pytest.mark.parametrize("case", cases.GUIDE_SHORT_CASES, ids=lambda c: c[0])
+def test_value_guidance_on_the_widest_transition(case):
+    """ValueGuidedPolicy on the Door architecture (td = 67, jittered affine), loop truncated to a few
+    steps of the T = 1000 schedule."""
+    name, net, T, n_steps, B, gw = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    sched = od.schedule_buffers("cosine", T)
+    noise = torch.from_numpy(cases.loop_noise(name, net, n_steps, B))
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net))}
+    od_dim = cases.net_dims(net)[0]
+    guide_fn = _value_fn(od_dim)
+    x = od.sample_loop(w, sched, noise, n_steps, cond, guide_fn=guide_fn, guide_weight=gw)
+    assert max_abs(x.numpy(), g["x_final"]) <= 5e-6
+    x0 = noise[0].clone()
+    x0[:, 0] = cond[0]
+    t = torch.full((B,), n_steps - 1, dtype=torch.long)
+    grad = od.guide_gradient(guide_fn, x0, t)
+    assert max_abs(grad.numpy(), g["first_grad"]) <= TOL
+    assert np.all(grad.numpy()[:, :, od_dim:] == 0)
     with torch.no_grad():
         step = od.denoise_step(w, sched, x0, t, noise[1], cond, grad, gw)
     assert max_abs(step.numpy(), g["first_step"]) <= TOL
