@@ -43,6 +43,7 @@ class DadProjectArgs(C.Structure):
         ("P", C.c_void_p), ("obs_mean", C.c_void_p), ("obs_std", C.c_void_p),
         ("act_mean", C.c_void_p), ("act_std", C.c_void_p),
         ("state_dim", C.c_int32), ("observation_dim", C.c_int32), ("action_dim", C.c_int32),
+        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
     ]
 
 
@@ -483,6 +484,8 @@ class ProjectionState:
         a.state_dim, a.observation_dim, a.action_dim = state_dim, observation_dim, action_dim
         self.args = a
         self.device = dev
+        self._scratch = None
+        self.gemm = True          # batches of 32+ trajectories: v @ P as an MFMA GEMM (needs the scratch copy)
         self.D = int(self.P.shape[0])
         if self.P.dim() != 2 or self.P.shape[1] != self.D:
             raise ValueError(f"projection matrix must be square, got {tuple(self.P.shape)}")
@@ -504,6 +507,12 @@ class ProjectionState:
                                f"{self.D}x{self.D}): the projector was built for another horizon")
         if x.device != self.P.device:
             raise RuntimeError(f"x is on {x.device}, the projector on {self.P.device}")
+        # scratch copy of the batch for the GEMM form (grown on demand; stable address while the batch
+        # size repeats, so captured loops keep their pointer)
+        if self.gemm and (self._scratch is None or self._scratch.numel() < x.numel()):
+            self._scratch = torch.empty(x.numel(), dtype=torch.float32, device=self.device)
+            self.args.scratch = self._scratch.data_ptr()
+            self.args.scratch_bytes = self._scratch.numel() * 4
 
     def violation(self, x: torch.Tensor) -> torch.Tensor:
         """Per-row squared distance from the dynamics-consistent subspace, physical units

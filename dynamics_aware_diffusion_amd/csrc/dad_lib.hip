@@ -46,6 +46,7 @@ unsigned long long* g_stamps = nullptr;
 struct GraphKey {
     const void* x; const void* noise; const void* cond; const void* ws;
     const void* P; const void* obs_mean; const void* obs_std; const void* act_mean; const void* act_std;
+    const void* proj_scratch;
     int n_steps, batch, cond_per_row, state_dim, observation_dim, action_dim;
     int force_tile, flags;    // tile / split-K / fusion hooks change the captured launches
     uint64_t row_offset;
@@ -557,12 +558,27 @@ int run_project(const dad_project_args* pa, float alpha, float* x, int batch, in
     p.alpha = alpha;
     p.one_minus_alpha = (float)(1.0 - (double)alpha);
     p.violation = violation;
+    // batches of 32+ trajectories with scratch for the projected copy: v @ P as an MFMA GEMM (P read once
+    // per 32 trajectories, not once per trajectory)
+    const size_t x_bytes = (size_t)batch * horizon * (pa->observation_dim + pa->action_dim) * sizeof(float);
+    if (!violation && batch >= 32 && pa->scratch != nullptr && pa->scratch_bytes >= x_bytes) {
+        p.xout = pa->scratch;
+        const dim3 grid((unsigned)((batch + 31) / 32), (unsigned)((p.D + 31) / 32));
+        hipLaunchKernelGGL(dad::project_gemm_kernel, grid, dim3(dad::PG_THREADS),
+                           dad::project_gemm_lds_floats() * sizeof(float), st, p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(x, pa->scratch, x_bytes, hipMemcpyDeviceToDevice, st));
+        return DAD_OK;
+    }
+    p.xout = x;
     // rows per block: one while the batch fits one wave of blocks (every CU streams P once),
     // four beyond that (P is then re-used by four rows per pass) if four rows fit LDS
     const size_t row_lds = (size_t)(1 + 16) * p.D * sizeof(float);    // a row + its 16 partial sets
     const int rb = (batch > 512 && 4 * row_lds <= dad::kLdsBytes) ? 4 : 1;
     const size_t lds = rb * row_lds;
-    if (lds > dad::kLdsBytes) return fail(DAD_E_INVALID, "projection dimension D=%d too large", p.D);
+    if (lds > dad::kLdsBytes)
+        return fail(DAD_E_INVALID, "projection dimension D=%d: one trajectory's partial sums exceed LDS; pass "
+                    "dad_project_args.scratch and a batch of at least 32 for the GEMM form", p.D);
     if (rb == 1)
         hipLaunchKernelGGL((dad::project_kernel<1, 16>), dim3(batch), dim3(1024), lds, st, p);
     else
@@ -865,6 +881,7 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     if (proj) {
         key.P = proj->P; key.obs_mean = proj->obs_mean; key.obs_std = proj->obs_std;
         key.act_mean = proj->act_mean; key.act_std = proj->act_std;
+        key.proj_scratch = proj->scratch;
         key.state_dim = proj->state_dim; key.observation_dim = proj->observation_dim;
         key.action_dim = proj->action_dim;
     }

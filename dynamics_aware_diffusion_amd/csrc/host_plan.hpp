@@ -665,6 +665,10 @@ inline bool tile_valid(const ConvOp& op, int cfg) {
     const int nthreads = 64 * (t.BM / 32) * (t.BN / 32) * t.SK;
     const int f4pl = t.BM * t.BN / 4 / nthreads;
     if (!op.norm.empty() && op.Lout * cpg / 4 < f4pl) return false;   // >= 1 lane per (group, sample)
+    // the stage must fit LDS (the 128-position tiles with the 128-channel chunk of a 1x1 conv do not)
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    if (dad::conv_lds_floats(t.BM, t.BN, kc, op.taps, op.Lin, op.Lout, t.SK, op.bdir, op.taps) * sizeof(float) > dad::kLdsBytes)
+        return false;
     return true;
 }
 inline int choose_tile(const HostModel& m, const ConvOp& op, int batch) {

@@ -219,6 +219,8 @@ struct ProjParams {
     const float* P;          // [D][D]
     const float* obs_mean; const float* obs_std; const float* act_mean; const float* act_std;
     float* x;                // (B,H,od+m) in place
+    float* xout;             // project_gemm_kernel: where the projected trajectories go (a scratch copy:
+                             // other blocks still gather from x); the caller copies it back over x
     int32_t B, H, n, od, m, D;
     float alpha, one_minus_alpha;
     float* violation;        // when set: x is left untouched and violation[b] = sum_d (v - vP)_d^2 in
@@ -320,6 +322,109 @@ __global__ __launch_bounds__(64 * KP) void project_kernel(const ProjParams p) {
             const int ts = rem / extra, k = rem - ts * extra;
             const int b = b0 + r;
             if (b < p.B) p.x[((long)b * H + ts) * td + n + k] = 0.0f;
+        }
+    }
+}
+
+// The same projection as a GEMM (batches of 32+ trajectories, any D): C[b][d] = sum_k v[b][k] P[k][d] on
+// v_mfma_f32_32x32x2_f32.  One block = 32 trajectories x 32 columns of P; its four waves split K in
+// chunks of 64 and meet in LDS (fixed order).  P is read once per 32 trajectories (straight from L2 /
+// Infinity Cache into the B operand: lane (column, k half) reads P[k][d0 + column], 128 contiguous bytes
+// per half wave) instead of once per trajectory; v is gathered + de-normalised from x chunk by chunk into
+// a wave-private LDS tile.  The epilogue blends and scatters its 32 x 32 outputs
+// (guides/policies.py:451-483) into a scratch copy of the batch (other blocks are still gathering from
+// x); the host copies it back.  No atomics: bit-reproducible.
+constexpr int PG_THREADS = 256;
+constexpr int PG_KC = 64;                     // k values per staged chunk
+constexpr int PG_AS = 33;                     // LDS row stride of the staged v chunk [k][32 rows]
+__host__ __device__ inline size_t project_gemm_lds_floats() { return (size_t)4 * PG_KC * PG_AS + 64; }
+
+// element d of trajectory row `xb` in physical units (policies.py:434-448)
+__device__ __forceinline__ float proj_gather(const ProjParams& p, const float* xb, int d, int nstate, int td) {
+    if (d < nstate) {
+        const int ts = d / p.n, k = d - ts * p.n;
+        const int tsrc = ts < p.H ? ts : p.H - 1;
+        return xb[tsrc * td + k] * p.obs_std[k] + p.obs_mean[k];
+    }
+    const int dd = d - nstate;
+    const int ts = dd / p.m, k = dd - ts * p.m;
+    return xb[ts * td + p.od + k] * p.act_std[k] + p.act_mean[k];
+}
+
+__global__ __launch_bounds__(PG_THREADS) void project_gemm_kernel(const ProjParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    const int D = p.D, H = p.H, td = p.od + p.m;
+    const int nstate = (H + 1) * p.n;
+    const int b0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    float* const As = sm + wave * (PG_KC * PG_AS);          // this wave's [64 k][32 rows (+1)]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nchunks = (D + PG_KC - 1) / PG_KC;
+    const int dcol = min(d0 + l32, D - 1);                  // (columns past D read column D-1 and are dropped)
+    for (int ch = wave; ch < nchunks; ch += 4) {
+        const int k0 = ch * PG_KC;
+        // B operand: 32 k-pairs of this chunk, all loads in flight before the gather
+        float bv[PG_KC / 2];
+#pragma unroll
+        for (int j = 0; j < PG_KC / 2; ++j) {
+            const int k = min(k0 + 2 * j + h, D - 1);       // (rows past D: masked by the zero A operand)
+            bv[j] = p.P[(long)k * D + dcol];
+        }
+        // A operand: lane = k of the chunk, loop over the 32 trajectories
+        {
+            const int k = k0 + lane;
+            for (int r = 0; r < 32; ++r) {
+                const int b = b0 + r;
+                float v = 0.0f;
+                if (k < D && b < p.B) v = proj_gather(p, p.x + (long)b * H * td, k, nstate, td);
+                As[lane * PG_AS + r] = v;
+            }
+        }
+        // (wave-private tile: the wave's own LDS writes are ordered before its reads by the waitcnt the
+        // compiler inserts; no block barrier inside the K loop)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < PG_KC / 2; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * j + h) * PG_AS + l32], bv[j], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    float* const E = sm;                                    // [4 waves][32 rows][33]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        E[(wave * 32 + row) * PG_AS + l32] = acc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += PG_THREADS) {
+        const int r = e >> 5, cidx = e & 31;
+        const int b = b0 + r, d = d0 + cidx;
+        if (b >= p.B || d >= D) continue;
+        const float proj = ((E[r * PG_AS + cidx] + E[(32 + r) * PG_AS + cidx]) + E[(64 + r) * PG_AS + cidx]) +
+                           E[(96 + r) * PG_AS + cidx];
+        const float vv = proj_gather(p, p.x + (long)b * H * td, d, nstate, td);
+        const float blended = p.alpha * proj + p.one_minus_alpha * vv;
+        float* xb = p.xout + (long)b * H * td;
+        if (d < nstate) {
+            const int ts = d / p.n, k = d - ts * p.n;
+            if (ts < H) xb[ts * td + k] = (blended - p.obs_mean[k]) / p.obs_std[k];
+        } else {
+            const int dd = d - nstate;
+            const int ts = dd / p.m, k = dd - ts * p.m;
+            xb[ts * td + p.od + k] = (blended - p.act_mean[k]) / p.act_std[k];
+        }
+    }
+    // observation channels beyond the physical state are zero-padded (policies.py:475-480)
+    if (p.od > p.n && blockIdx.y == 0) {
+        const int extra = p.od - p.n;
+        for (int e = tid; e < 32 * H * extra; e += PG_THREADS) {
+            const int r = e / (H * extra);
+            const int rem = e - r * H * extra;
+            const int ts = rem / extra, k = rem - ts * extra;
+            if (b0 + r < p.B) p.xout[((long)(b0 + r) * H + ts) * td + p.n + k] = 0.0f;
         }
     }
 }

@@ -208,6 +208,12 @@ typedef struct dad_project_args {
     int32_t state_dim;      /* n */
     int32_t observation_dim;/* od (== n in every reachable reference configuration)  */
     int32_t action_dim;     /* m */
+    /* Optional device scratch of at least batch * H * (od + m) floats, owned by the caller.  With it,
+     * batches of 32+ trajectories run v @ P as an MFMA GEMM that reads P once per 32 trajectories
+     * (required beyond D = 2000, where one trajectory's partial sums no longer fit a CU's LDS);
+     * without it every trajectory streams P on its own. */
+    float* scratch;
+    size_t scratch_bytes;
 } dad_project_args;
 
 int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,

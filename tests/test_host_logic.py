@@ -466,16 +466,19 @@ print("rank", rank, "ok")
 """
 
 
-@pytest.mark.parametrize("total", [8, 7])
-def test_two_rank_gather_over_gloo(tmp_path, total):
-    """world_size-2 CPU rehearsal of the multi-GPU path: shard -> sample -> gather."""
+@pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (8, 1024), (8, 21)],
+                         ids=["w2_8", "w2_7ragged", "w8_1024_config5", "w8_21ragged"])
+def test_sharded_gather_over_gloo(tmp_path, world, total):
+    """CPU rehearsal of the multi-GPU path over gloo: shard -> sample -> gather, at world size 2 and at
+    BASELINE config 5's shape (8 ranks x 128 = 1024 plans; equal shards: one all_gather_into_tensor) plus
+    ragged splits."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + total + os.getpid() % 200),
-               WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (total * 7 + world + os.getpid()) % 400),
+               WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(total)],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}:\n{out}"
