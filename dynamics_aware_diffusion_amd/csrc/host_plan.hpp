@@ -751,7 +751,10 @@ inline SplitPlan plan_split(const HostModel& m, const ConvOp& op, int cfg, int b
     SplitPlan sp{1, nchunks, 0};
     if (!m.split_enabled) return sp;
     if (tiles >= 160 || nchunks < 2 || tiles > kMaxSplitTiles) return sp;
-    int want = (int)((m.split_target + tiles - 1) / tiles);
+    // blocks = tiles * slices should not spill a few blocks into a second wave of the 256 CUs (24 tiles x
+    // 11 slices = 264 blocks took 1.4x the time of 24 x 10): round the slice count DOWN while that still
+    // splits, up only for tile counts above half the chip
+    int want = tiles * 2 <= m.split_target ? (int)(m.split_target / tiles) : (int)((m.split_target + tiles - 1) / tiles);
     if (want > nchunks) want = nchunks;
     if (want < 2) return sp;
     sp.chunks_per_slice = (nchunks + want - 1) / want;

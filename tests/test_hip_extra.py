@@ -147,6 +147,51 @@ def test_frozen_fuzz_draws_match_oracle(draw, dev):
     assert max_abs(got.cpu().numpy(), want.numpy()) <= TOL_STEP
 
 
+@pytest.mark.parametrize("net,B", [("halfcheetah", 8), ("halfcheetah", 12), ("door", 16)])
+def test_wide_nets_at_a_few_environments_default_path(net, B, dev):
+    """`get_actions` for 8..16 environments on the wide nets: past `ccw_max_rows` the batch takes the
+    batch-256 kernels with grid-level split-K (whole slices rounded so that tiles x slices stays within one
+    wave of the 256 CUs) — against the oracle, default settings."""
+    from dynamics_aware_diffusion_amd.utils import synth
+    diff = build(net, cases.NETS[net][4], "cosine", dev)
+    assert diff._engine(dev).small_batch_plan(B) == (0, 0)
+    x = torch.from_numpy(synth.normal_like(83, f"mid.{net}.{B}", (B, 32, diff.transition_dim)))
+    want = _oracle_eps(net, x, 640).numpy()
+    got = diff.model(x.to(dev), 640).cpu().numpy()
+    assert max_abs(got, want) <= TOL_STEP
+
+
+def test_eight_environments_cost_less_per_plan_than_four(dev):
+    """on HalfCheetah a denoise step for 8 plans takes at most 1.5x the step for 4
+    (measured 720 vs 625 us), i.e. `get_actions(8 envs)` is cheaper per plan than two calls of 4."""
+    import time
+    from dynamics_aware_diffusion_amd import GuidedPolicy
+    diff = build("halfcheetah", 1000, "cosine", dev)
+    diff.sampler_rng, diff.seed, diff.use_graph = "philox", 5, True
+    keep = diff.n_timesteps
+    diff.n_timesteps = 60
+    pol = GuidedPolicy(diff, None)
+    cond = {0: torch.from_numpy(cases.loop_condition("mid", "halfcheetah")).to(dev)}
+    us = {}
+    try:
+        for B in (4, 8):
+            pol.sample_loop(batch_size=B, conditions=cond)             # capture + warm
+            best = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pol.sample_loop(batch_size=B, conditions=cond)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) * 1e6 / diff.n_timesteps)
+            us[B] = best
+    finally:
+        diff.n_timesteps = keep
+        diff.use_graph = False
+        diff.sampler_rng = "torch"
+    print(f"HalfCheetah denoise step: B=4 {us[4]:.0f} us, B=8 {us[8]:.0f} us")
+    assert us[8] <= 1.5 * us[4]
+
+
 @pytest.mark.parametrize("net,B", [("halfcheetah", 1), ("halfcheetah", 2), ("halfcheetah", 5), ("halfcheetah", 16),
                                    ("door", 1), ("door", 3), ("door", 4), ("door", 16)])
 def test_wide_nets_small_batches_take_the_streamed_weight_kernels(net, B, dev):
