@@ -52,6 +52,12 @@ WORKLOADS = {
                                  "(noise_schedule, strength 1), batch=256/GPU"),
     "pointmaze_noproj_t500_b256": ("pointmaze", 256, 500, 3,
                                    "PointMaze dynamics-aware policy as shipped (no projection), T=500, batch=256/GPU"),
+    # the same loop with a value guide (ValueGuidedPolicy, guides/policies.py:243-271): the guide's gradient
+    # comes from torch autograd on the user's value module every step, so the loop is driven from Python
+    # (one dad_denoise_step per iteration, no hipGraph); value net = Linear(4,16) -> tanh -> Linear(16,1)
+    "pointmaze_guided_b256": ("pointmaze", 256, 100, 2,
+                              "PointMaze umaze-v2 VALUE-guided policy (tiny MLP value net, guide_weight 0.1), "
+                              "H=32 dim=128 T=100 batch=256/GPU"),
     "halfcheetah_b128": ("halfcheetah", 128, 1000, 4,
                          "HalfCheetah medium-v2, H=32 dim=256 mults(1,4,8) T=1000 batch=128/GPU"),
     "door_b128": ("door", 128, 1000, 5,
@@ -66,7 +72,7 @@ WORKLOADS = {
 }
 # the other BASELINE configurations timed after the headline, in this order (+ the two batch-1
 # calls on the wide nets)
-EXTRA_CONFIGS = ["pointmaze_b1", "pointmaze_proj_t500_b256", "halfcheetah_b128", "door_b128",
+EXTRA_CONFIGS = ["pointmaze_b1", "pointmaze_proj_t500_b256", "pointmaze_guided_b256", "halfcheetah_b128", "door_b128",
                  "halfcheetah_b1", "door_b1"]
 
 
@@ -193,6 +199,13 @@ def main() -> None:
                                              state_dim=4, observation_dim=od, action_dim=ad, horizon=32,
                                              projection_schedule="noise_schedule", projection_strength=1.0,
                                              project_during_sampling=not workload.startswith("pointmaze_noproj"))
+        elif "guided" in workload:
+            from dynamics_aware_diffusion_amd import ValueGuidedPolicy
+            value = torch.nn.Sequential(torch.nn.Linear(od, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1)).to(device)
+            with torch.no_grad():
+                for i, prm in enumerate(value.parameters()):
+                    prm.copy_(torch.from_numpy(synth.uniform(31, f"bench.value.{i}", tuple(prm.shape), 0.7)))
+            policy = ValueGuidedPolicy(diff, None, value, guide_weight=0.1)
         else:
             policy = GuidedPolicy(diff, normalizer=None)
         cond = torch.zeros(1, td)

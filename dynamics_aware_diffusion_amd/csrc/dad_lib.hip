@@ -959,6 +959,7 @@ struct WgradGeom { int spc, ksplit, sps; unsigned gx, gy; size_t lds; };
 WgradGeom wgrad_geom(int M, int Ctot, int B, int Lg, int Lz, int taps, int pad) {
     WgradGeom g{};
     g.spc = std::max(1, dad::WG_ROWS / Lg);
+    while (g.spc > 1 && g.spc * dad::wgrad_segz(Lz, taps, pad) > 160) g.spc /= 2;     // the kernel stages <= 160 Z rows
     g.gx = (unsigned)((M + dad::WG_TILE - 1) / dad::WG_TILE);
     g.gy = (unsigned)((Ctot + dad::WG_TILE - 1) / dad::WG_TILE);
     const long tiles = (long)g.gx * g.gy;
@@ -1099,7 +1100,7 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
         return DAD_OK;
     };
     auto col_sums = [&](float* out, const float* p, int C) -> int {
-        hipLaunchKernelGGL(dad::col_sums_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, out, p, B, C, C);
+        hipLaunchKernelGGL(dad::col_sums_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, out, p, B, C, C);
         HIP_TRY(hipGetLastError());
         return DAD_OK;
     };
@@ -1111,7 +1112,8 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
     auto wgrad = [&](const float* Gp, int ldg, int M, const float* Z0, int C0, const float* Z1, int C1, float* out,
                      int taps, int stride, int pad, int Lg, int Lz) -> int {
         const WgradGeom g = wgrad_geom(M, C0 + C1, B, Lg, Lz, taps, pad);
-        if (g.lds > dad::kLdsBytes) return fail(DAD_E_INVALID, "wgrad: a chunk of %d x %d rows does not fit LDS", g.spc, Lz);
+        if (g.lds > dad::kLdsBytes || g.spc * Lg > 128 || g.spc * dad::wgrad_segz(Lz, taps, pad) > 160)
+            return fail(DAD_E_INVALID, "wgrad: a chunk of %d samples x %d rows exceeds the kernel's staging", g.spc, Lz);
         dad::WgradParams p{};
         p.G = Gp; p.ldg = ldg; p.M = M;
         p.Z0 = Z0; p.ldz0 = C0; p.C0 = C0; p.Z1 = Z1; p.ldz1 = C1; p.C1 = C1;

@@ -82,30 +82,56 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+    // A chunk = spc whole samples: G rows [spc * Lg][64] and Z rows with their zero halo [spc * SEGZ][64].
+    // The loads of chunk i + 1 are issued before the MFMA loop of chunk i and land under it (registers:
+    // up to WG_GI + WG_ZI float4 per thread), then go to LDS behind the barrier.
+    constexpr int WG_GI = 8, WG_ZI = 10;                     // covers 128 G rows / 160 Z rows per chunk
+    const int n_g = spc * Lg * (WG_TILE / 4), n_z = spc * SEGZ * (WG_TILE / 4);
+    float4 gr[WG_GI], zr[WG_ZI];
+    auto chunk_load = [&](int sb) {
+#pragma unroll
+        for (int k = 0; k < WG_GI; ++k) {
+            const int i = tid + k * WG_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n_g) {
+                const int row = i >> 4, q = i & 15;
+                const int smp = sb + (row >> p.lg_shift), l = row & (Lg - 1);
+                if (smp < s_hi) v = wg_load4(p.G + (long)(smp * Lg + l) * p.ldg, m0 + 4 * q, p.M, gvec);
+            }
+            gr[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < WG_ZI; ++k) {
+            const int i = tid + k * WG_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n_z) {
+                const int row = i >> 4, q = i & 15;
+                const int sl = row / SEGZ, pz = row - sl * SEGZ - p.pad;
+                const int smp = sb + sl;
+                const int c = c0 + 4 * q;
+                if (smp < s_hi && pz >= 0 && pz < Lz && c < Ctot) {
+                    if (c < p.C0) v = wg_load4(p.Z0 + (long)(smp * Lz + pz) * p.ldz0, c, p.C0, z0vec);
+                    else v = wg_load4(p.Z1 + (long)(smp * Lz + pz) * p.ldz1, c - p.C0, p.C1, z1vec);
+                }
+            }
+            zr[k] = v;
+        }
+    };
+    chunk_load(s_lo);
     for (int sb = s_lo; sb < s_hi; sb += spc) {
         __syncthreads();                                     // the previous chunk's fragment reads are done
-        // ---- stage G rows of samples [sb, sb + spc)
-        for (int i = tid; i < spc * Lg * (WG_TILE / 4); i += WG_THREADS) {
-            const int row = i >> 4, q = i & 15;
-            const int smp = sb + (row >> p.lg_shift), l = row & (Lg - 1);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (smp < s_hi) v = wg_load4(p.G + (long)(smp * Lg + l) * p.ldg, m0 + 4 * q, p.M, gvec);
-            *reinterpret_cast<float4*>(Gs + row * WG_TILE + 4 * q) = v;
+#pragma unroll
+        for (int k = 0; k < WG_GI; ++k) {
+            const int i = tid + k * WG_THREADS;
+            if (i < n_g) *reinterpret_cast<float4*>(Gs + (i >> 4) * WG_TILE + 4 * (i & 15)) = gr[k];
         }
-        // ---- stage Z rows with their zero halo
-        for (int i = tid; i < spc * SEGZ * (WG_TILE / 4); i += WG_THREADS) {
-            const int row = i >> 4, q = i & 15;
-            const int sl = row / SEGZ, pz = row - sl * SEGZ - p.pad;
-            const int smp = sb + sl;
-            const int c = c0 + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (smp < s_hi && pz >= 0 && pz < Lz && c < Ctot) {
-                if (c < p.C0) v = wg_load4(p.Z0 + (long)(smp * Lz + pz) * p.ldz0, c, p.C0, z0vec);
-                else v = wg_load4(p.Z1 + (long)(smp * Lz + pz) * p.ldz1, c - p.C0, p.C1, z1vec);
-            }
-            *reinterpret_cast<float4*>(Zs + row * WG_TILE + 4 * q) = v;
+#pragma unroll
+        for (int k = 0; k < WG_ZI; ++k) {
+            const int i = tid + k * WG_THREADS;
+            if (i < n_z) *reinterpret_cast<float4*>(Zs + (i >> 4) * WG_TILE + 4 * (i & 15)) = zr[k];
         }
         __syncthreads();
+        if (sb + spc < s_hi) chunk_load(sb + spc);           // in flight under the MFMAs below
         // ---- K loop over the chunk's rows: k = row (lane half h takes row kk + h)
         const int nrows = spc * Lg;
         for (int kk = 0; kk < nrows; kk += 2) {
@@ -161,13 +187,32 @@ __global__ void row_partial_sums_kernel(float* part, const float* g, int L, int 
     }
 }
 
-// out[c] = sum_b part[b * stride + c], b in order
-__global__ void col_sums_kernel(float* out, const float* part, int B, int stride, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.0f;
-    for (int b = 0; b < B; ++b) acc += part[(long)b * stride + c];
-    out[c] = acc;
+// out[c] = sum_b part[b * stride + c].  Block = 32 columns x 8 row groups: thread (col, rg) adds rows
+// rg, rg + 8, ... (four independent chains of loads in flight), the eight partials meet in LDS and are
+// added in group order — fixed order, bit-reproducible.  grid = ceil(C / 32), 256 threads.
+__global__ __launch_bounds__(256) void col_sums_kernel(float* out, const float* part, int B, int stride, int C) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        int b = rg;
+        for (; b + 24 < B; b += 32) {
+            a0 += part[(long)b * stride + c];
+            a1 += part[(long)(b + 8) * stride + c];
+            a2 += part[(long)(b + 16) * stride + c];
+            a3 += part[(long)(b + 24) * stride + c];
+        }
+        for (; b < B; b += 8) a0 += part[(long)b * stride + c];
+    }
+    red[rg][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float v = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += red[k][col];
+        out[c] = v;
+    }
 }
 
 // --------------------------------------------------------------------- GroupNorm + Mish backward

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Time one training step's device work (GaussianDiffusion.loss forward + loss.backward()) on the HIP engine:
+
+    python3 profiles/train_step_timing.py --arch pointmaze --batch 256
+
+Reports ms for the training forward, the backward pass, and the algorithmic conv TFLOP/s (backward = 2x the
+forward's conv FLOPs: data gradient + weight gradient).  The engine is rebuilt when parameters change (weights
+are re-packed on the host), so the timed region re-uses one engine: it measures kernels, not the re-pack."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet  # noqa: E402
+from dynamics_aware_diffusion_amd.utils import synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--arch", default="pointmaze", choices=sorted(synth.ARCHS))
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--repeats", type=int, default=5)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+od, ad, dim, mults, T = synth.ARCHS[args.arch]
+td = od + ad
+unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+unet.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_unet_state(td, dim, mults, seed=0).items()})
+diff = GaussianDiffusion(unet, 32, od, ad, n_timesteps=T).to(dev)
+x0 = torch.from_numpy(synth.normal_like(3, "train.x0", (args.batch, 32, td))).to(dev).clamp(-1, 1)
+f = synth.unet_flops_per_sample(td, dim, mults, 32) * args.batch
+fwd, bwd = [], []
+for rep in range(args.repeats + 1):
+    for p in diff.parameters():
+        p.grad = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = diff.loss(x0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    loss.backward()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    if rep:
+        fwd.append(t1 - t0)
+        bwd.append(t2 - t1)
+fm, bm = min(fwd) * 1e3, min(bwd) * 1e3
+print(f"{args.arch} B={args.batch}: training forward {fm:.2f} ms ({f / fm / 1e9:.1f} TFLOP/s), backward {bm:.2f} ms "
+      f"({2 * f / bm / 1e9:.1f} TFLOP/s algorithmic), loss {float(loss):.5f}", flush=True)
