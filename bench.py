@@ -468,6 +468,59 @@ def main() -> None:
         torch.cuda.empty_cache()
         return out
 
+    def training_step():
+        """one training step's device work on the headline architecture — the
+        differentiable GaussianDiffusion.loss (training forward: every activation kept) and loss.backward()
+        through the engine's explicit backward pass — next to the oracle's autograd on the host cores."""
+        arch, batch = "pointmaze", 256
+        od, ad, dim, mults, T = synth.ARCHS[arch]
+        td = od + ad
+        unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+        state = synth.synth_unet_state(td, dim, mults, seed=0)
+        unet.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        diff = GaussianDiffusion(unet, 32, od, ad, n_timesteps=T).to(device)
+        x0 = torch.from_numpy(synth.normal_like(3, "train.x0", (batch, 32, td))).to(device).clamp(-1, 1)
+        fwd, bwd = [], []
+        for rep in range(4):
+            for prm in diff.parameters():
+                prm.grad = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.enable_grad():
+                loss = diff.loss(x0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loss.backward()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if rep:
+                fwd.append(t1 - t0)
+                bwd.append(t2 - t1)
+        f = synth.unet_flops_per_sample(td, dim, mults, 32) * batch
+        out = {"workload": f"{arch} batch {batch}: GaussianDiffusion.loss + loss.backward() (fp32)",
+               "forward_ms": min(fwd) * 1e3, "backward_ms": min(bwd) * 1e3,
+               "samples_per_s": batch / (min(fwd) + min(bwd)),
+               "backward_conv_tflops_algorithmic": 2 * f / min(bwd) / 1e12,
+               "note": "host work included (time MLPs and loss in torch, workspace allocation); weights are re-packed "
+                       "on the host when parameters change — not part of this figure"}
+        if not args.no_cpu_baseline:
+            from oracle import denoiser as od_
+            cores = usable_cores()
+            torch.set_num_threads(cores)
+            cb = 32
+            w = {k: torch.from_numpy(v) for k, v in state.items()}
+            sched = od_.schedule_buffers("cosine", T)
+            xs = x0[:cb].cpu()
+            tt = torch.arange(cb) % T
+            nz = torch.from_numpy(synth.normal_like(3, "train.noise", (cb, 32, td)))
+            od_.training_gradients(w, sched, xs, tt, nz)
+            t0 = time.perf_counter()
+            od_.training_gradients(w, sched, xs, tt, nz)
+            el = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": cb / el, "unit": "samples/s", "cores": cores, "kind": "port",
+                                   "sample": f"one oracle forward + autograd backward of batch {cb} ({el:.2f} s)"}
+        return out
+
     head = run_workload(args.workload, args.steps, args.warmup, headline=True)
     configs = None
     if not args.no_configs and args.inflight == 1:
@@ -486,6 +539,13 @@ def main() -> None:
                     raise                          # ranks must stay in step: fail loudly
                 configs[name] = {"error": repr(exc)}
 
+    training = None
+    if rank == 0 and world == 1 and configs is not None:
+        try:
+            training = training_step()
+        except Exception as exc:                   # noqa: BLE001
+            training = {"error": repr(exc)}
+
     if rank == 0:
         line = {
             "metric": head["metric"], "value": head["value"], "unit": "plans/s", "n_gpus": world,
@@ -494,7 +554,7 @@ def main() -> None:
             "dtype": "f32" if args.precision == "fp32" else "f16x3 (split-f16 operand pairs, f32 accumulate)",
             "data": "synthetic", "config": head["config"], "roofline": head["roofline"],
             "cpu_baseline": head["cpu_baseline"], "alt_precision": head.get("alt_precision"),
-            "configs": configs,
+            "configs": configs, "training_step": training,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -85,6 +85,8 @@ ABI = {
     "dad_debug_small_batch_plan": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                              C.POINTER(C.c_int32)]),
     "dad_model_set_training": (C.c_int, [C.c_void_p, C.c_int32]),
+    "dad_model_refresh_weights": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
+                                            C.c_void_p]),
     "dad_train_grad_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "dad_train_grad_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64)]),
@@ -368,6 +370,23 @@ class HipEngine:
                 self._stream()))
 
     # ------------------------------------------------------------------ training
+    def refresh(self, unet_state: Mapping[str, torch.Tensor]) -> None:
+        """Re-derive the engine's packed copies from parameter tensors that already live on this device
+        (fp32, contiguous): no host round trip (dad_model_refresh_weights)."""
+        keys, ptrs, keep = [], [], []
+        for key, t in unet_state.items():
+            d = t.detach()
+            if d.device != self.device or d.dtype != torch.float32 or not d.is_contiguous():
+                d = d.to(self.device, torch.float32).contiguous()
+            keep.append(d)
+            keys.append(key.encode())
+            ptrs.append(d.data_ptr())
+        n = len(keys)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.dad_model_refresh_weights(
+                self._h, n, (C.c_char_p * n)(*keys), (C.c_void_p * n)(*ptrs), self._stream()))
+        self._refresh_keep = keep          # (stream-ordered: the copies run before anything enqueued later)
+
     def grad_layout(self):
         """[(reference key without 'model.', offset in floats, numel)] of the flat gradient buffer and
         its total length."""

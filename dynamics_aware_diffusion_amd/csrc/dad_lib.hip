@@ -73,6 +73,8 @@ struct dad_model : HostModel {
     uint64_t* d_rng = nullptr;
     unsigned* d_counters = nullptr;   // split-K arrival tickets (zero between launches)
     float* d_zero = nullptr;          // zeros: bias row of the data-gradient launches (training)
+    std::map<std::string, float*> d_time;    // time-MLP tensors as uploaded (dad_model_refresh_weights re-derives the tables)
+    float* d_h1 = nullptr;            // [T][4 time_dim] scratch of the table builder
     std::vector<void*> owned;         // every hipMalloc to free
     // All parameters, tables and flags live in ONE device allocation: a conv launch touches a
     // handful of pages instead of one page per tensor (cold address translations used to cost
@@ -587,6 +589,32 @@ int run_project(const dad_project_args* pa, float alpha, float* x, int batch, in
     return DAD_OK;
 }
 
+// Per-timestep tables from the device copies of the time-MLP tensors: time_mlp (Linear -> Mish -> Linear
+// on the sinusoid rows) and every block's Mish -> Linear (temporal_unet.py:97-100,155-160).
+int build_time_tables(dad_model* m, hipStream_t st) {
+    const dad_cfg& c = m->cfg;
+    const int T = c.n_timesteps, dim = c.dim, tdm = c.time_dim;
+    auto linear = [&](const float* in, const std::string& key, float* out, int K, int M, int stride, int mish_in) -> int {
+        auto w = m->d_time.find(key + ".weight"), b = m->d_time.find(key + ".bias");
+        if (w == m->d_time.end() || b == m->d_time.end()) return fail(DAD_E_KEY, "missing key '%s'", key.c_str());
+        const long total = (long)T * M;
+        hipLaunchKernelGGL(dad::table_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                           0, st, in, w->second, b->second, out, T, K, M, stride, mish_in);
+        HIP_TRY(hipGetLastError());
+        return DAD_OK;
+    };
+    int rc;
+    if ((rc = linear(m->d_emb, "time_mlp.1", m->d_h1, dim, 4 * tdm, 4 * tdm, 0)) != DAD_OK) return rc;
+    if ((rc = linear(m->d_h1, "time_mlp.3", m->d_temb, 4 * tdm, tdm, tdm, 1)) != DAD_OK) return rc;
+    for (const ConvOp& op : m->plan.convs) {
+        if (op.temb_off < 0) continue;
+        std::string base = op.name.substr(0, op.name.size() - std::strlen(".blocks.0.block.0"));
+        if ((rc = linear(m->d_temb, base + ".time_mlp.1", m->d_temb_table + op.temb_off, tdm, op.cout,
+                         m->plan.temb_width, 1)) != DAD_OK) return rc;
+    }
+    return DAD_OK;
+}
+
 }  // namespace
 
 // ===================================================================================== ABI
@@ -737,8 +765,8 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     // expression), else the same formula with the C library's expf/sinf/cosf
     const std::vector<float> emb = m->emb_override.size() == (size_t)T * dim ? m->emb_override
                                                                             : sinusoid_table(T, dim);
-    float *d_emb, *d_h1, *d_temb, *d_w, *d_b;
-    (void)c;
+    float *d_emb, *d_h1, *d_temb;
+    (void)c; (void)dim;
     if ((rc = upload(m, emb, &d_emb)) != DAD_OK) return rc;
     std::vector<float> zeros((size_t)T * 4 * tdm, 0.0f);
     if ((rc = upload(m, zeros, &d_h1)) != DAD_OK) return rc;
@@ -746,26 +774,15 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
     if ((rc = upload(m, zeros, &d_temb)) != DAD_OK) return rc;
     zeros.assign((size_t)T * std::max(1, m->plan.temb_width), 0.0f);
     if ((rc = upload(m, zeros, &m->d_temb_table)) != DAD_OK) return rc;
-    m->d_emb = d_emb; m->d_temb = d_temb;
-    auto linear = [&](const float* in, const std::string& key, float* out, int K, int M, int stride,
-                      int mish_in) -> int {
-        int r;
-        if ((r = upload(m, m->raw[key + ".weight"].data, &d_w)) != DAD_OK) return r;
-        if ((r = upload(m, m->raw[key + ".bias"].data, &d_b)) != DAD_OK) return r;
-        const long total = (long)T * M;
-        hipLaunchKernelGGL(dad::table_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-                           0, st, in, d_w, d_b, out, T, K, M, stride, mish_in);
-        HIP_TRY(hipGetLastError());
-        return DAD_OK;
-    };
-    if ((rc = linear(d_emb, "time_mlp.1", d_h1, dim, 4 * tdm, 4 * tdm, 0)) != DAD_OK) return rc;
-    if ((rc = linear(d_h1, "time_mlp.3", d_temb, 4 * tdm, tdm, tdm, 1)) != DAD_OK) return rc;
-    for (const ConvOp& op : m->plan.convs) {
-        if (op.temb_off < 0) continue;
-        std::string base = op.name.substr(0, op.name.size() - std::strlen(".blocks.0.block.0"));
-        if ((rc = linear(d_temb, base + ".time_mlp.1", m->d_temb_table + op.temb_off, tdm, op.cout,
-                         m->plan.temb_width, 1)) != DAD_OK) return rc;
-    }
+    m->d_emb = d_emb; m->d_temb = d_temb; m->d_h1 = d_h1;
+    m->d_time.clear();
+    for (const auto& kv : m->raw)                        // every time-MLP tensor keeps a device copy
+        if (kv.first.find("time_mlp.") != std::string::npos) {
+            float* dptr = nullptr;
+            if ((rc = upload(m, kv.second.data, &dptr)) != DAD_OK) return rc;
+            m->d_time[kv.first] = dptr;
+        }
+    if ((rc = build_time_tables(m, st)) != DAD_OK) return rc;
     void* rng = nullptr;
     if ((rc = arena_alloc(m, 64, &rng)) != DAD_OK) return rc;
     m->d_rng = (uint64_t*)rng;
@@ -933,6 +950,94 @@ int dad_model_set_training(dad_model* m, int32_t on) {
     if (on) if (const char* why = training_refusal(*m)) return fail(DAD_E_INVALID, "training: %s", why);
     if ((on != 0) != m->training) m->finalized = false;       // the data-gradient images are packed at finalize
     m->training = on != 0;
+    return DAD_OK;
+}
+
+int dad_model_refresh_weights(dad_model* m, int32_t n, const char* const* keys, const float* const* tensors,
+                              dad_stream_t stream) {
+    if (!m || n < 0 || (n > 0 && (!keys || !tensors))) return fail(DAD_E_INVALID, "bad argument");
+    if (!m->finalized) return fail(DAD_E_STATE, "dad_model_finalize has not been called");
+    if (m->precision != DAD_PREC_FP32)
+        return fail(DAD_E_STATE, "the split-f16 images are scaled per layer on the host: load the weights and finalize again");
+    hipStream_t st = (hipStream_t)stream;
+    auto repack = [&](float* dst, const ConvOp& op, int mode, const float* w, const float* ride, int CO, int CI, int K,
+                      int c_lo, int c_n) -> int {
+        dad::RepackParams p{};
+        p.dst = dst; p.w = w; p.ride = ride;
+        p.kg = op.bdir ? 16 : std::min(op.kc, 16);
+        p.wtaps = op.wtaps(); p.M = op.M;
+        p.n = (long)op.cin_pad * p.wtaps * op.M;
+        p.mode = mode; p.CO = CO; p.CI = CI; p.K = K; p.c_lo = c_lo; p.c_n = c_n;
+        hipLaunchKernelGGL(dad::repack_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+        HIP_TRY(hipGetLastError());
+        return DAD_OK;
+    };
+    auto copy = [&](float* dst, const float* src, size_t floats) -> int {
+        HIP_TRY(hipMemcpyAsync(dst, src, floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return DAD_OK;
+    };
+    std::map<std::string, const float*> given;
+    for (int i = 0; i < n; ++i) {
+        if (!keys[i] || !tensors[i]) return fail(DAD_E_INVALID, "null key or tensor at index %d", i);
+        if (!m->expected.count(keys[i])) return fail(DAD_E_KEY, "unexpected key '%s'", keys[i]);
+        given[keys[i]] = tensors[i];
+    }
+    auto has = [&](const std::string& k) -> const float* { auto it = given.find(k); return it == given.end() ? nullptr : it->second; };
+    bool tables_dirty = false;
+    int rc;
+    for (auto& kv : given)
+        if (kv.first.find("time_mlp.") != std::string::npos) {
+            const auto& shape = m->expected[kv.first];
+            size_t fl = 1;
+            for (int64_t d : shape) fl *= (size_t)d;
+            if ((rc = copy(m->d_time.at(kv.first), kv.second, fl)) != DAD_OK) return rc;
+            tables_dirty = true;
+        }
+    std::vector<ConvOp>& convs = m->plan.convs;
+    for (size_t i = 0; i < convs.size(); ++i) {
+        ConvOp& op = convs[i];
+        const int cin = op.cin0 + op.cin1;
+        const float* w = has(op.name + ".weight");
+        const float* rw = op.ride ? has(op.rname + ".weight") : nullptr;
+        if (w || rw) {
+            // the image holds this conv's taps and, when a 1x1 residual conv rides along, that conv's weights
+            // as an extra tap: both are needed to rebuild it
+            if (op.ride && (!w || !rw))
+                return fail(DAD_E_KEY, "'%s.weight' and '%s.weight' share one packed image: refresh them together",
+                            op.name.c_str(), op.rname.c_str());
+            rc = op.kind == CONV_UP ? repack(op.d_w, op, dad::RP_FWD_UP, w, nullptr, op.cout, cin, 4, 0, 0)
+                                    : repack(op.d_w, op, dad::RP_FWD, w, rw, op.cout, cin, op.taps, 0, 0);
+            if (rc != DAD_OK) return rc;
+            if (m->training && w) {
+                const HostModel::BwdConv& b = m->bconvs[i];
+                for (int k = 0; k < b.n; ++k) {
+                    const ConvOp& bo = b.op[k];
+                    const int mode = op.kind == CONV_DOWN ? dad::RP_BWD_DOWN : op.kind == CONV_UP ? dad::RP_BWD_UP : dad::RP_BWD_CONV;
+                    if ((rc = repack(bo.d_w, bo, mode, w, nullptr, op.cout, cin, op.taps, b.c_lo[k], b.c_n[k])) != DAD_OK) return rc;
+                }
+            }
+        }
+        if (const float* bsrc = has(op.name + ".bias")) {
+            if ((rc = copy(op.d_bias, bsrc, op.cout)) != DAD_OK) return rc;
+            if (op.kind == CONV_UP && (rc = copy(op.d_bias + op.cout, bsrc, op.cout)) != DAD_OK) return rc;
+        }
+        if (op.ride)
+            if (const float* rb = has(op.rname + ".bias"))
+                if ((rc = copy(op.d_rbias, rb, op.cout)) != DAD_OK) return rc;
+        if (!op.norm.empty()) {
+            if (const float* g = has(op.norm + ".weight")) if ((rc = copy(op.d_gamma, g, op.cout)) != DAD_OK) return rc;
+            if (const float* be = has(op.norm + ".bias")) if ((rc = copy(op.d_beta, be, op.cout)) != DAD_OK) return rc;
+        }
+    }
+    if (const float* fw = has("final_conv.1.weight")) {
+        if ((rc = copy(m->d_final_w, fw, (size_t)m->cfg.transition_dim * m->cfg.dim)) != DAD_OK) return rc;
+        if (m->training &&
+            (rc = repack(m->bfinal.d_w, m->bfinal, dad::RP_BWD_FINAL, fw, nullptr, m->cfg.transition_dim, m->cfg.dim, 1, 0, 0)) != DAD_OK)
+            return rc;
+    }
+    if (const float* fb = has("final_conv.1.bias"))
+        if ((rc = copy(m->d_final_b, fb, m->cfg.transition_dim)) != DAD_OK) return rc;
+    if (tables_dirty && (rc = build_time_tables(m, st)) != DAD_OK) return rc;
     return DAD_OK;
 }
 

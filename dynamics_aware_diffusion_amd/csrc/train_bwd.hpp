@@ -158,6 +158,63 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------ device-side weight re-packing
+// dad_model_refresh_weights: a training loop changes the parameters every step; the packed images
+// (csrc/host_plan.hpp pack_op / pack_bwd_op) are rebuilt ON THE DEVICE from the parameter tensors in the
+// reference's layouts, one thread per element of the image (padding included, so no memset):
+//   image index = (((ci / kg) * wtaps + slot) * M + o) * kg + ci % kg
+enum RepackMode {
+    RP_FWD = 0,        // Conv1d (co, ci, K) [+ riding 1x1 conv as slot K]
+    RP_FWD_UP = 1,     // ConvTranspose1d (ci, co, 4) as two 2-tap phases, M = 2 co
+    RP_BWD_CONV = 2,   // data gradient of Conv1d: (m, c, K-1-slot) <- W[c][c_lo + m][.]
+    RP_BWD_DOWN = 3,   // data gradient of Downsample1d as a transposed conv whose 4th tap is zero
+    RP_BWD_UP = 4,     // data gradient of Upsample1d as a 5-tap stride-2 conv whose first tap is zero
+    RP_BWD_FINAL = 5,  // data gradient of final_conv[1]
+};
+struct RepackParams {
+    float* dst; const float* w; const float* ride;     // ride: the 1x1 residual conv's weight, or nullptr
+    long n;                                            // elements of the image
+    int32_t mode, kg, wtaps, M;
+    int32_t CO, CI, K;                                 // the SOURCE tensor's dims as the mode reads them
+    int32_t c_lo, c_n;                                 // RP_BWD_CONV: input-channel range of the forward conv
+};
+__global__ void repack_kernel(const RepackParams p) {
+    const long d = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= p.n) return;
+    const int j = (int)(d % p.kg);
+    long r = d / p.kg;
+    const int o = (int)(r % p.M);
+    r /= p.M;
+    const int slot = (int)(r % p.wtaps);
+    const int ci = (int)(r / p.wtaps) * p.kg + j;
+    float v = 0.0f;
+    switch (p.mode) {
+        case RP_FWD:
+            if (ci < p.CI) {
+                if (slot < p.K) v = p.w[((long)o * p.CI + ci) * p.K + slot];
+                else if (p.ride != nullptr) v = p.ride[(long)o * p.CI + ci];
+            }
+            break;
+        case RP_FWD_UP: case RP_BWD_DOWN: {
+            const int co = p.M >> 1, half = o >= co, oo = o - half * co;
+            const int kk = half == 0 ? (slot == 0 ? 3 : 1) : (slot == 0 ? 2 : 0);
+            if (p.mode == RP_FWD_UP) { if (ci < p.CI) v = p.w[((long)ci * co + oo) * 4 + kk]; }
+            else if (ci < p.CO && kk < 3) v = p.w[((long)ci * p.CI + oo) * 3 + kk];       // W (co_f = ci, ci_f = oo, k)
+            break;
+        }
+        case RP_BWD_CONV:
+            if (o < p.c_n && ci < p.CO) v = p.w[((long)ci * p.CI + p.c_lo + o) * p.K + (p.K - 1 - slot)];
+            break;
+        case RP_BWD_UP:
+            if (slot >= 1 && o < p.CI && ci < p.CO) v = p.w[((long)o * p.CO + ci) * 4 + (slot - 1)];   // Wt (ci_f = o, co_f = ci, kk)
+            break;
+        case RP_BWD_FINAL:
+            if (ci < p.CO) v = p.w[(long)ci * p.CI + o];                                      // Wf (td = ci, dim = o)
+            break;
+    }
+    p.dst[d] = v;
+}
+
 // out[i] = sum_k slab[k][i], k in order
 __global__ void sum_slabs_kernel(float* out, const float* slab, long n, int ks) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -98,6 +98,7 @@ class TemporalUnet(nn.Module):
         # engine state (not part of state_dict)
         self._engine: Optional[HipEngine] = None
         self._engine_sig = None
+        self._engine_params = None
         self._schedule: Optional[Dict[str, torch.Tensor]] = None
         self._diffusion_opts = {"n_timesteps": 1000, "predict_epsilon": True,
                                 "clip_denoised": True}
@@ -113,12 +114,13 @@ class TemporalUnet(nn.Module):
                                 "clip_denoised": bool(clip_denoised)}
 
     def _signature(self, horizon: int, device: torch.device):
+        """(what the engine's structure depends on, the parameters' identities and versions)"""
         params = tuple((p.data_ptr(), p._version) for p in self.parameters())
         opts = tuple(sorted(self._diffusion_opts.items()))
         sched = None
         if self._schedule is not None:
             sched = tuple((k, v.data_ptr(), v._version) for k, v in sorted(self._schedule.items()))
-        return (horizon, str(device), opts, params, sched, self.precision, bool(self.small_batch_kernels))
+        return (horizon, str(device), opts, sched, self.precision, bool(self.small_batch_kernels)), params
 
     def engine(self, horizon: int, device: torch.device, training: bool = False) -> HipEngine:
         """Return the engine for (horizon, device), (re)building it if weights, schedule or
@@ -128,9 +130,16 @@ class TemporalUnet(nn.Module):
             raise RuntimeError(
                 "TemporalUnet runs on the HIP engine only: move the model and its inputs to a "
                 f"ROCm device (got {device}); there is no CPU fallback")
-        sig = self._signature(horizon, device)
+        sig, params = self._signature(horizon, device)
         if self._engine is not None and sig == self._engine_sig and (self._engine.training or not training):
-            return self._engine
+            if params == self._engine_params:
+                return self._engine
+            if self.precision == "fp32" and all(p.device == device for p in self.parameters()):
+                # only parameter VALUES changed (an optimiser step): the packed copies are re-derived on the
+                # device, no engine rebuild and no host round trip
+                self._engine.refresh(dict(self.named_parameters()))
+                self._engine_params = params
+                return self._engine
         opts = self._diffusion_opts
         T = opts["n_timesteps"]
         eng = HipEngine(transition_dim=self.transition_dim, dim=self.dim, channels=self.channels,
@@ -147,7 +156,7 @@ class TemporalUnet(nn.Module):
                                        "posterior_log_variance_clipped")}
         eng.load(dict(self.named_parameters()), sched)
         eng.debug_set_option("cc", int(bool(self.small_batch_kernels)))
-        self._engine, self._engine_sig = eng, sig
+        self._engine, self._engine_sig, self._engine_params = eng, sig, params
         return eng
 
     # ------------------------------------------------------------------ forward

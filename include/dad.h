@@ -147,6 +147,15 @@ int dad_unet_forward_rows(dad_model* m, const float* x, const int32_t* t_rows, f
  * reference's own layout (Conv1d (out, in, k); ConvTranspose1d (in, out, k)).  The time-MLP tensors are
  * not in the list. */
 int dad_model_set_training(dad_model* m, int32_t on);
+/* Replaces: nothing in the reference (its modules ARE the parameters); here the engine holds packed copies,
+ * and an optimiser step (utils/training.py:166) changes the parameters every iteration.  Re-derives, ON THE
+ * DEVICE, everything the engine keeps of the given tensors — packed conv images (forward and, in training
+ * mode, the data-gradient images), biases, GroupNorm affine parameters, the per-timestep time tables — from
+ * DEVICE fp32 tensors in the reference's layouts (same keys as dad_model_load_weight).  A conv whose block's
+ * 1x1 residual conv rides in its image needs both weights in the same call.  fp32 arithmetic only.
+ * Asynchronous on `stream`; captured loops stay valid (the images are updated in place). */
+int dad_model_refresh_weights(dad_model* m, int32_t n, const char* const* keys, const float* const* tensors,
+                              dad_stream_t stream);
 int dad_train_grad_count(const dad_model* m, int32_t* count, int64_t* total_floats);
 int dad_train_grad_info(const dad_model* m, int32_t i, const char** key, int64_t* offset, int64_t* numel);
 /* saved: every activation of one forward (nothing is overwritten before the backward pass reads it);

@@ -150,3 +150,50 @@ def test_training_refusals(dev):
             diff.model(torch.zeros(2, cases.H, 6, device=dev), torch.zeros(2, dtype=torch.long, device=dev))
     finally:
         diff.model.precision = "fp32"
+
+
+def test_sgd_steps_track_the_oracle_without_leaving_the_device(dev):
+    """Three optimiser steps (utils/training.py:152-166: loss, backward, step) on the HIP engine against the
+    same three steps of torch autograd on the oracle.  After every step the engine re-derives its packed
+    images on the device (dad_model_refresh_weights: forward images, data-gradient images, time tables) —
+    the engine object must survive the steps — and the sampler's inference kernels must see the new weights."""
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    from oracle import denoiser as orc
+    net, T, B, lr = "tiny4", 20, 5, 0.05
+    od, ad, td, dim, mults = cases.net_dims(net)
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet.load_state_dict({k: torch.from_numpy(v) for k, v in cases.net_weights(net).items()})
+    diff = GaussianDiffusion(unet, cases.H, od, ad, n_timesteps=T).to(dev)
+    opt = torch.optim.SGD(diff.model.parameters(), lr=lr)
+    w = {k: v.clone() for k, v in net_weights_torch(net).items()}
+    sched = orc.schedule_buffers("cosine", T)
+    engines = set()
+    for step in range(3):
+        x0, t, noise, _ = cases.train_inputs(f"sgd.{step}", net, T, B, False)
+        tt = torch.from_numpy(t).to(dev)
+        real_randint = torch.randint
+        torch.randint = lambda *a, **k: tt.clone()
+        try:
+            with injected_noise(noise[None], dev), torch.enable_grad():
+                opt.zero_grad()
+                loss = diff.loss(torch.from_numpy(x0).to(dev))
+                loss.backward()
+                opt.step()
+        finally:
+            torch.randint = real_randint
+        engines.add(id(diff.model._engine))
+        ol, og, _ = orc.training_gradients(w, sched, torch.from_numpy(x0), torch.from_numpy(t), torch.from_numpy(noise))
+        w = {k: v - lr * og[k] for k, v in w.items()}
+        assert abs(float(loss) - float(ol)) <= 5e-6 * max(1.0, abs(float(ol))), (step, float(loss), float(ol))
+    torch.cuda.synchronize()
+    assert len(engines) == 1, "the engine was rebuilt instead of refreshed"
+    for k, p in diff.model.named_parameters():
+        assert max_abs(p.detach().cpu().numpy(), w[k].numpy()) <= 2e-5 * max(1.0, float(w[k].abs().max())), k
+    # inference kernels (per-timestep tables, small-batch plan) on the updated weights
+    x = torch.from_numpy(cases.forward_input("sgd.fwd", net, 3))
+    with torch.no_grad():
+        want = orc.unet_forward(w, x, torch.full((3,), 7, dtype=torch.long))
+        got = diff.model(x.to(dev), 7)
+    torch.cuda.synchronize()
+    assert len({id(diff.model._engine)} | engines) == 1
+    assert max_abs(got.cpu().numpy(), want.numpy()) <= 2e-5
