@@ -146,7 +146,7 @@ template <int CFG> struct Tile {
 template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR, bool RES>
 void reg_kernel(KernTable& t) {
     using T = Tile<CFG>;
-    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR);
+    constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR, T::BN);
     t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, false, RES)] =
         dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR, RES>;
     if constexpr (!BDIR && STRIDE == 1 && (TAPS == 5 || TAPS == 1))    // general staging path

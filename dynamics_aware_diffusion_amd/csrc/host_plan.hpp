@@ -117,9 +117,10 @@ constexpr TileCfg kTiles[kNumTiles] = {
 // 1x1 convs have one (tap, group) unit per 8 channels: a deep K chunk keeps enough MFMAs between
 // barriers (128 channels; 64 for the 128-row tile, whose stage would not fit LDS twice).
 // Split-f16 kernels consume 16 channels per unit: the chunk must give every split-K wave a unit.
-constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false, bool bd = false) {
+// (128-position tiles: a 32-channel chunk — the deep one would not fit LDS twice next to 128 rows.)
+constexpr int eff_kc(int cfg_kc, int bm, int taps, int sk = 1, bool x3 = false, bool bd = false, int bn = 64) {
     return bd                          ? 32          // wide tile, direct-B kernel (either arithmetic)
-           : (taps == 1 && cfg_kc >= 16) ? (bm >= 128 ? 64 : 128)
+           : (taps == 1 && cfg_kc >= 16) ? (bn >= 128 ? 32 : bm >= 128 ? 64 : 128)
            : (x3 && cfg_kc < 16 * sk)  ? 16 * sk
                                        : cfg_kc;
 }
@@ -666,7 +667,7 @@ inline bool tile_valid(const ConvOp& op, int cfg) {
     const int f4pl = t.BM * t.BN / 4 / nthreads;
     if (!op.norm.empty() && op.Lout * cpg / 4 < f4pl) return false;   // >= 1 lane per (group, sample)
     // the stage must fit LDS (the 128-position tiles with the 128-channel chunk of a 1x1 conv do not)
-    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir, t.BN);
     if (dad::conv_lds_floats(t.BM, t.BN, kc, op.taps, op.Lin, op.Lout, t.SK, op.bdir, op.taps) * sizeof(float) > dad::kLdsBytes)
         return false;
     return true;
@@ -746,7 +747,7 @@ inline SplitPlan plan_split(const HostModel& m, const ConvOp& op, int cfg, int b
     const TileCfg& t = kTiles[cfg];
     const int spt = t.BN / op.Lout;
     const long tiles = (long)((batch + spt - 1) / spt) * (op.M / t.BM);
-    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir, t.BN);
     const int nchunks = (op.cin0 + op.cin1 + kc - 1) / kc;      // chunks holding real channels
     SplitPlan sp{1, nchunks, 0};
     if (!m.split_enabled) return sp;
@@ -801,7 +802,7 @@ inline bool fused_at(const HostModel& m, const ConvOp& op, int batch) {
     if (cfg < 0) return false;
     const TileCfg& t = kTiles[cfg];
     if (t.KC < 16 || plan_split(m, op, cfg, batch).kslices != 1) return false;
-    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    const int kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir, t.BN);
     return dad::conv_lds_floats(t.BM, t.BN, kc, op.taps, op.Lin, op.Lout, t.SK, false, op.taps + 1) *
                sizeof(float) <= dad::kLdsBytes;
 }
@@ -815,7 +816,7 @@ inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g)
         return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d)",
                     op.name.c_str(), op.M, op.cout / 8, op.Lout);
     const TileCfg& t = kTiles[g.cfg];
-    g.kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir);
+    g.kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir, t.BN);
     const int cin = op.cin0 + op.cin1;
     g.ragged = (op.cin0 & 3) != 0 || (op.cin1 & 3) != 0 || op.cin0 % g.kc != 0 || cin % g.kc != 0;
     if (g.ragged && !(op.stride == 1 && (op.taps == 5 || op.taps == 1)))
