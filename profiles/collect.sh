@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r02'
+#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r03'
 # Pass 1   kernel trace + stats of the bench command (timings the JSON line must agree with).
 # Pass 2-4 counter passes, one counter family each (FETCH_SIZE and WRITE_SIZE do not fit one pass;
 #          gpurun refuses --pmc together with runtime traces), on profiles/pmc_target.py: ONE eager
@@ -10,7 +10,7 @@
 # note (log tail + file listing), and ENDS the script: nothing further is started on a GPU a killed
 # profiler may have left in an unknown state, and there is no re-run knob.
 set -uo pipefail
-tag="${1:-r02}"
+tag="${1:-r03}"
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out/profiles_$tag"
 mkdir -p "$out"
@@ -49,6 +49,19 @@ for cfg in "halfcheetah 128" "door 128" "pointmaze 1" "halfcheetah 1" "door 1"; 
   run_pass "trace_$1_b$2" 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$1_b$2_$stamp" -- "${target[@]}" --arch "$1" --batch "$2" --denoise-steps 20
   run_pass "fetch_$1_b$2" 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch_$1_b$2_$stamp" -- "${target[@]}" --arch "$1" --batch "$2" --denoise-steps 20
   run_pass "write_$1_b$2" 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write_$1_b$2_$stamp" -- "${target[@]}" --arch "$1" --batch "$2" --denoise-steps 20
+done
+# BASELINE config 3: the projected loop (projection kernel time and bytes)
+run_pass trace_pointmaze_proj 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_pointmaze_proj_$stamp" -- "${target[@]}" --project
+run_pass fetch_pointmaze_proj 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch_pointmaze_proj_$stamp" -- "${target[@]}" --project
+run_pass write_pointmaze_proj 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write_pointmaze_proj_$stamp" -- "${target[@]}" --project
+# one training step (forward + backward) of the headline architecture
+run_pass trace_train 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_train_$stamp" -- python3 "$root/profiles/train_step_timing.py" --arch pointmaze --batch 256 --repeats 3
+# per-layer efficiency tables (batch-256 kernels)
+for cfg in "pointmaze 256" "halfcheetah 128" "door 128"; do
+  set -- $cfg
+  t=$(ls "$out"/trace_$1_b$2_$stamp/*/*_kernel_trace.csv 2>/dev/null | head -1)
+  [ "$1" = pointmaze ] && t=$(ls "$out"/pmc_sq_$stamp/*/*_kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$t" ] && python3 "$root/profiles/layer_table.py" "$t" "$1" "$2" > "$root/gpurun_out/${tag}_layers_$1_b$2.md" 2> "$out/layers_$1_b$2.err" || true
 done
 echo "[collect] bench"
 timeout -k 10 600 python3 "$root/bench.py" --steps 5 --warmup 2 > "$out/bench_$stamp.json" 2> "$out/bench_$stamp.err"

@@ -178,6 +178,54 @@ for arch, batch, workload in (("halfcheetah", 128, "halfcheetah_b128"), ("door",
         cur[workload] = entry["hbm_bytes_per_conv_launch"]
         json.dump(cur, open(tpath, "w"), indent=1)
     others[tag2] = entry
+# ---- BASELINE config 3: the projected loop — conv launches + the projection kernels of every step
+tr = one("trace_pointmaze_proj_*/**/*_kernel_trace.csv")
+if tr:
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(tr)):
+        if "dad::" in r["Kernel_Name"] or "copyBuffer" in r["Kernel_Name"]:
+            a = agg[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    steps = sum(n for k, (n, t) in agg.items() if "final_" in k)
+    conv = [(n, t) for k, (n, t) in agg.items() if "conv_" in k]
+    proj = {k: {"calls": n, "avg_us": t / n} for k, (n, t) in agg.items() if "project" in k}
+    entry = {"command": "python3 profiles/pmc_target.py --project   (PointMaze B=256, projection after every step, D = 196)",
+             "denoise_steps_traced": steps,
+             "conv_launches_per_denoise_step": sum(n for n, _ in conv) / max(1, steps),
+             "projection_kernels": proj,
+             "projection_us_per_denoise_step": sum(v["calls"] * v["avg_us"] for v in proj.values()) / max(1, steps),
+             "all_kernels_us_per_denoise_step": sum(t for k, (n, t) in agg.items() if "dad::" in k) / max(1, steps)}
+    st = one("trace_pointmaze_proj_*/**/*_kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(here, f"{tag}_kernel_stats_pointmaze_proj.csv"))
+
+    def pmc_kind(dirname, counter, needle):
+        f = one(f"{dirname}_*/**/*_counter_collection.csv")
+        if not f:
+            return None
+        tot = 0.0
+        for r in csv.DictReader(open(f)):
+            if needle in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                tot += float(r["Counter_Value"])
+        return tot
+    fe, wr = pmc_kind("fetch_pointmaze_proj", "FETCH_SIZE", "dad::"), pmc_kind("write_pointmaze_proj", "WRITE_SIZE", "dad::")
+    fp, wp = pmc_kind("fetch_pointmaze_proj", "FETCH_SIZE", "project"), pmc_kind("write_pointmaze_proj", "WRITE_SIZE", "project")
+    if fe is not None and wr is not None and steps:
+        nconv = max(1, sum(n for n, _ in conv))
+        entry["hbm_bytes_per_denoise_step"] = (2.0 * fe + wr) * 1024.0 / steps
+        entry["projection_hbm_bytes_per_denoise_step"] = (2.0 * (fp or 0.0) + (wp or 0.0)) * 1024.0 / steps
+        # what bench.py reports as roofline.traffic for config 3: every kernel's bytes of a step (the
+        # projection's included), per conv launch
+        entry["hbm_bytes_per_conv_launch_incl_projection"] = (2.0 * fe + wr) * 1024.0 / nconv
+        tpath = os.path.join(here, "traffic.json")
+        cur = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        cur["pointmaze_proj_t500_b256"] = entry["hbm_bytes_per_conv_launch_incl_projection"]
+        json.dump(cur, open(tpath, "w"), indent=1)
+    others["pointmaze_proj_b256"] = entry
+st = one("trace_train_*/**/*_kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(here, f"{tag}_kernel_stats_train_step.csv"))
 if others:
     summary["other_configs"] = others
 

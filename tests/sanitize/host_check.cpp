@@ -282,6 +282,80 @@ static void check_arch(const Arch& a, int precision) {
         for (size_t k = 0; k + 1 < spans.size(); ++k) CHECK(spans[k].second <= spans[k + 1].first, "CC slabs overlap");
         if (!spans.empty()) CHECK(spans.front().first >= 0 && spans.back().second <= cc.slab_floats, "CC slabs outside their region");
     }
+    // training plan + backward plan (fp32): every tensor of the forward owns its buffer, the data-gradient
+    // launches find a tile at every batch, their packed images are permutations of the weights, and the flat
+    // gradient buffer holds every conv / GroupNorm / final-conv tensor exactly once
+    long bwd_launches = 0;
+    if (precision == DAD_PREC_FP32 && training_refusal(m) == nullptr) {
+        const Plan& T = m.tplan;
+        CHECK(T.convs.size() == P.convs.size() && m.bconvs.size() == T.convs.size(), "training plan size");
+        std::vector<int> writers(T.bufs.size(), 0);
+        for (const ConvOp& op : T.convs) {
+            ++writers[op.dst];
+            CHECK(op.norm.empty() == (op.pre < 0) && (op.pre < 0) == (op.stats < 0), "%s: pre / stats buffers", op.name.c_str());
+            if (op.pre >= 0) {
+                ++writers[op.pre]; ++writers[op.stats];
+                CHECK(T.bufs[op.pre].per_sample >= (long)op.cout * op.Lout && T.bufs[op.stats].per_sample >= 16, "%s: pre / stats size", op.name.c_str());
+            }
+        }
+        for (size_t i = 0; i < writers.size(); ++i) CHECK(writers[i] <= 1, "training buffer %zu written by %d launches", i, writers[i]);
+        for (size_t i = 0; i < T.bufs.size(); ++i) CHECK(T.bufs[i].offset + T.bufs[i].per_sample <= T.floats_per_sample, "training buffer %zu overruns", i);
+        std::map<std::string, int> seen;
+        long end = 0;
+        for (const auto& gs : m.grad_slots) {
+            ++seen[gs.key];
+            CHECK(gs.offset >= end && gs.offset % 4 == 0, "gradient slot %s overlaps", gs.key.c_str());
+            end = gs.offset + gs.numel;
+            auto ex = m.expected.find(gs.key);
+            CHECK(ex != m.expected.end(), "gradient slot %s is not a parameter", gs.key.c_str());
+            if (ex != m.expected.end()) {
+                long n = 1;
+                for (int64_t d : ex->second) n *= (long)d;
+                CHECK(n == gs.numel, "gradient slot %s: %ld elements, parameter has %ld", gs.key.c_str(), gs.numel, n);
+            }
+        }
+        CHECK(end <= m.grad_numel, "gradient buffer too short");
+        for (const auto& kv : m.expected)
+            if (kv.first.find("time_mlp.") == std::string::npos) CHECK(seen[kv.first] == 1, "parameter %s has %d gradient slots", kv.first.c_str(), seen[kv.first]);
+        for (size_t i = 0; i < T.convs.size(); ++i) {
+            const ConvOp& f = T.convs[i];
+            const HostModel::BwdConv& b = m.bconvs[i];
+            CHECK(b.n == (f.cin1 > 0 ? 2 : 1), "%s: %d data-gradient launches", f.name.c_str(), b.n);
+            int covered = 0;
+            for (int k = 0; k < b.n; ++k) {
+                covered += b.c_n[k];
+                CHECK(b.op[k].cout >= b.c_n[k] && b.op[k].cout % 32 == 0 && b.op[k].cin0 == f.cout, "%s: data-gradient shape", f.name.c_str());
+                for (int B : {1, 3, 9, 32, 256}) {
+                    LaunchGeom g;
+                    rc = plan_launch(m, b.op[k], B, g);
+                    CHECK(rc == DAD_OK, "%s B=%d: %s", b.op[k].name.c_str(), B, g_err);
+                    if (rc == DAD_OK) { ++bwd_launches; CHECK(g.lds_bytes <= dad::kLdsBytes && !g.fused, "%s: geometry", b.op[k].name.c_str()); }
+                }
+                if (a.pack) {
+                    std::vector<float> img;
+                    rc = pack_bwd_op(&m, f, b, k, img);
+                    CHECK(rc == DAD_OK && img.size() == (size_t)b.op[k].cin_pad * b.op[k].wtaps() * b.op[k].M, "%s: data-gradient image", f.name.c_str());
+                    if (b.n == 1) {        // one source: the image is a permutation of the weight tensor plus zeros
+                        double s_in = 0, s_out = 0;
+                        for (float v : m.raw[f.name + ".weight"].data) s_in += v;
+                        for (float v : img) s_out += v;
+                        CHECK(std::fabs(s_in - s_out) <= 1e-5 * (1 + std::fabs(s_in)), "%s: data-gradient image checksum", f.name.c_str());
+                    }
+                }
+            }
+            CHECK(covered == f.cin0 + f.cin1, "%s: data gradients cover %d of %d input channels", f.name.c_str(), covered, f.cin0 + f.cin1);
+        }
+        for (int B : {1, 9, 256}) {
+            LaunchGeom g;
+            rc = plan_launch(m, m.bfinal, B, g);
+            CHECK(rc == DAD_OK, "final data gradient B=%d: %s", B, g_err);
+        }
+        if (a.pack) {
+            std::vector<float> img;
+            CHECK(pack_bwd_final(&m, img) == DAD_OK && img.size() == (size_t)m.bfinal.cin_pad * m.bfinal.M, "final data-gradient image");
+        }
+    }
+    (void)bwd_launches;
     printf("  %-14s prec=%d: %zu launches in the plan, %zu buffers, %ld floats/sample, %ld launch geometries checked\n",
            a.name, precision, P.convs.size(), P.bufs.size(), P.floats_per_sample, launches);
     (void)cc_plans;
@@ -301,6 +375,8 @@ int main(int argc, char** argv) {
         {"single", 3, 32, 32, 32, {1}, true},
         {"h8", 8, 128, 128, 8, {1, 4}, true},
         {"h64", 23, 64, 64, 64, {1, 1, 2}, true},
+        {"h128", 6, 128, 128, 128, {1, 2, 4}, true},
+        {"h128w", 23, 256, 256, 128, {1, 4, 8}, false},
     };
     // the fuzz generator's space (tests/fuzz_parity.py), deterministic sweep
     std::mt19937 rng(7);

@@ -197,3 +197,49 @@ def test_sgd_steps_track_the_oracle_without_leaving_the_device(dev):
     torch.cuda.synchronize()
     assert len({id(diff.model._engine)} | engines) == 1
     assert max_abs(got.cpu().numpy(), want.numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("arch", [
+    # (td, dim, mults, horizon, B)
+    (5, 256, (1, 8), 8, 3),            # 2048 channels: 256-channel GroupNorm groups (<256,32> direct-B tile), L = 8 / 4
+    (9, 128, (1, 8, 4), 16, 4),        # 1024 channels (128-channel groups, <128,64>), shrinking tail 1024 -> 512 is refused below
+    (7, 64, (1, 2, 4, 8), 32, 2),      # four levels, L down to 4: every down / up-sampling conv shape
+    (6, 128, (1, 2), 128, 2),          # horizon 128: the <32,128> tiles in the training forward and the data gradients
+], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}")
+def test_gradients_on_other_architectures_vs_oracle(arch, dev):
+    """The backward pass beyond the fixture nets: wide GroupNorm groups (the direct-B forward tile keeps the
+    pre-activation and statistics too), four levels, horizon 128 — every parameter gradient and dL/dx against
+    the oracle's autograd (pinned to the reference's own gradients in test_oracle_golden.py)."""
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    from dynamics_aware_diffusion_amd._engine import DadError
+    from dynamics_aware_diffusion_amd.utils import synth
+    from oracle import denoiser as orc
+    td, dim, mults, H, B = arch
+    T = 20
+    state = synth.synth_unet_state(td, dim, mults, seed=19, affine_jitter=0.3)
+    w = {k: torch.from_numpy(v) for k, v in state.items()}
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet.load_state_dict(w)
+    diff = GaussianDiffusion(unet, H, td - 1, 1, n_timesteps=T).to(dev)
+    x0 = torch.from_numpy(np.clip(synth.normal_like(20, f"garch.x.{arch}", (B, H, td)) * 0.5, -1, 1).astype(np.float32))
+    t = torch.from_numpy(np.array([(3 * i + 1) % T for i in range(B)], dtype=np.int64))
+    noise = torch.from_numpy(synth.normal_like(20, f"garch.n.{arch}", (B, H, td)))
+    shrinking = any(b < a for a, b in zip(mults, mults[1:]))
+    with torch.enable_grad():
+        x_t = diff.q_sample(x0.to(dev), t.to(dev), noise.to(dev)).detach().requires_grad_(True)
+        if shrinking:
+            with pytest.raises(DadError, match="identity residual over a channel concat"):
+                diff.model(x_t, t.to(dev))
+            return
+        out = diff.model(x_t, t.to(dev))
+        ((out - noise.to(dev)) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    _, og, odx = orc.training_gradients(w, orc.schedule_buffers("cosine", T), x0, t, noise)
+    assert max_abs(x_t.grad.cpu().numpy(), odx.numpy()) <= REL * float(odx.abs().max())
+    worst = 0.0
+    for k, p in diff.model.named_parameters():
+        scale = max(float(og[k].abs().max()), 1e-12)
+        e = max_abs(p.grad.cpu().numpy(), og[k].numpy()) / scale
+        worst = max(worst, e)
+        assert e <= REL, f"{k}: {e:.2e} x max|g|"
+    print(f"{arch}: worst parameter-gradient error {worst:.2e} x max|g|")
