@@ -25,6 +25,7 @@
 #include "conv_cc.hpp"
 #include "conv_ccw.hpp"
 #include "train_bwd.hpp"
+#include "conv_chain.hpp"
 
 using namespace dadhost;
 
@@ -73,6 +74,9 @@ struct dad_model : HostModel {
     uint64_t* d_rng = nullptr;
     unsigned* d_counters = nullptr;   // split-K arrival tickets (zero between launches)
     float* d_zero = nullptr;          // zeros: bias row of the data-gradient launches (training)
+    std::vector<dad::ChainConv> chain;       // level-0 chain (conv_chain.hpp): its five convs, or empty
+    std::vector<int> chain_src;              // plan index of each chain conv (its standard image feeds chain_repack_kernel)
+    int chain_C = 0, chain_last = -1;
     std::map<std::string, float*> d_time;    // time-MLP tensors as uploaded (dad_model_refresh_weights re-derives the tables)
     float* d_h1 = nullptr;            // [T][4 time_dim] scratch of the table builder
     std::vector<void*> owned;         // every hipMalloc to free
@@ -127,6 +131,7 @@ void free_device(dad_model* m) {
     m->d_rng = nullptr;
     m->d_counters = nullptr;
     m->d_zero = nullptr;
+    m->chain.clear(); m->chain_src.clear(); m->chain_C = 0; m->chain_last = -1;
     for (Plan* plan : {&m->plan, &m->tplan})
         for (auto& op : plan->convs) op.d_w = op.d_bias = op.d_gamma = op.d_beta = op.d_rbias = nullptr;
     for (auto& b : m->bconvs) for (int k = 0; k < b.n; ++k) b.op[k].d_w = b.op[k].d_bias = nullptr;
@@ -243,6 +248,9 @@ int configure_kernels() {
                         HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::final_cc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
@@ -467,7 +475,32 @@ int run_unet(dad_model* m, const float* x, int t, int batch, float* ws, hipStrea
         if (m->profile) HIP_TRY(hipEventRecord(e1, st));
         return DAD_OK;
     }
-    for (const ConvOp& op : convs) {
+    // level-0 chain: the first six plan entries as ONE launch (inference plan, shared timestep, large batch)
+    int first = 0;
+    if (!train && trow == nullptr && (int)m->chain.size() == dad::CH_N && m->chain_enabled && batch >= m->chain_min_batch) {
+        dad::ChainParams cp{};
+        cp.x = x;
+        cp.out = ws + plan.bufs[convs[m->chain_last].dst].offset * (long)batch;
+        cp.temb_row = m->d_temb_table + (long)t * m->plan.temb_width;
+        cp.B = batch; cp.td = m->cfg.transition_dim;
+        for (int i = 0; i < dad::CH_N; ++i) cp.c[i] = m->chain[i];
+        switch (m->chain_C) {
+            case 32: hipLaunchKernelGGL(dad::chain_l0_kernel<32>, dim3(batch), dim3(dad::ChainShape<32>::NT),
+                                        dad::ChainShape<32>::LDS_FLOATS * sizeof(float), st, cp); break;
+            case 64: hipLaunchKernelGGL(dad::chain_l0_kernel<64>, dim3(batch), dim3(dad::ChainShape<64>::NT),
+                                        dad::ChainShape<64>::LDS_FLOATS * sizeof(float), st, cp); break;
+            default: hipLaunchKernelGGL(dad::chain_l0_kernel<128>, dim3(batch), dim3(dad::ChainShape<128>::NT),
+                                        dad::ChainShape<128>::LDS_FLOATS * sizeof(float), st, cp); break;
+        }
+        HIP_TRY(hipGetLastError());
+        first = m->chain_last + 1;
+        if (m->profile) {
+            for (int i = 0; i < first; ++i) m->prof_flops += convs[i].flops_per_sample * batch;
+            ++m->prof_launches;
+        }
+    }
+    for (size_t oi = (size_t)first; oi < convs.size(); ++oi) {
+        const ConvOp& op = convs[oi];
         // a residual 1x1 conv whose block's first conv carries it at this batch is not launched
         const bool rides = op.rider_of >= 0 && fused_at(*m, convs[op.rider_of], batch);
         if (m->profile) m->prof_flops += op.flops_per_sample * batch;
@@ -593,6 +626,20 @@ int run_project(const dad_project_args* pa, float alpha, float* x, int batch, in
     return DAD_OK;
 }
 
+// The level-0 chain's weight images from the standard packed images of its convs (device side: also after
+// dad_model_refresh_weights).
+int repack_chain(dad_model* m, hipStream_t st) {
+    for (size_t k = 0; k < m->chain.size(); ++k) {
+        const ConvOp& op = m->plan.convs[m->chain_src[k]];
+        const int nch = (op.cin0 + 15) / 16;
+        const long n4 = (long)nch * 2 * op.wtaps() * (op.M / 32) * 64;
+        hipLaunchKernelGGL(dad::chain_repack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                           const_cast<float*>(m->chain[k].w), op.d_w, nch, op.wtaps(), op.M);
+        HIP_TRY(hipGetLastError());
+    }
+    return DAD_OK;
+}
+
 // Per-timestep tables from the device copies of the time-MLP tensors: time_mlp (Linear -> Mish -> Linear
 // on the sinusoid rows) and every block's Mish -> Linear (temporal_unet.py:97-100,155-160).
 int build_time_tables(dad_model* m, hipStream_t st) {
@@ -639,6 +686,7 @@ int dad_model_create(const dad_cfg* cfg, dad_model** out) {
     m->fuse_residual = getenv("DAD_NO_FUSE_RES") == nullptr;
     if (const char* v = getenv("DAD_SPLIT_TARGET")) m->split_target = std::max(1, atoi(v));
     m->cc_enabled = getenv("DAD_NO_CC") == nullptr;
+    m->chain_enabled = getenv("DAD_CHAIN") != nullptr;
     if (const char* v = getenv("DAD_CC_MAX_ROWS")) m->cc_max_rows = std::max(0, atoi(v));
     if ((rc = build_plan(m.get())) != DAD_OK) return rc;
     *out = m.release();
@@ -743,6 +791,33 @@ int dad_model_finalize(dad_model* m, dad_stream_t stream) {
         ConvOp& b = m->tplan.convs[i];
         b.d_w = a.d_w; b.d_bias = a.d_bias; b.d_gamma = a.d_gamma; b.d_beta = a.d_beta; b.d_rbias = a.d_rbias;
         b.c1 = a.c1; b.c2 = a.c2;
+    }
+    {   // level-0 chain table (conv_chain.hpp)
+        const ChainPlan cp = chain_plan(*m);
+        if (cp.ok) {
+            const std::vector<ConvOp>& v = m->plan.convs;
+            std::vector<dad::ChainConv> tab;
+            auto entry = [&](const ConvOp& op, int src, int dst, int add_t0, int ride) {
+                dad::ChainConv e{};
+                void* img = nullptr;                        // the chain's own image of this conv (filled below)
+                const int nch = (op.cin0 + 15) / 16;
+                if (arena_alloc(m, (size_t)nch * op.wtaps() * op.M * 16 * sizeof(float), &img) != DAD_OK) return;
+                m->chain_src.push_back((int)(&op - &v[0]));
+                e.w = (const float*)img; e.bias = op.d_bias; e.gamma = op.d_gamma; e.beta = op.d_beta; e.rbias = ride ? op.d_rbias : nullptr;
+                e.temb_off = op.temb_off; e.cin = op.cin0; e.taps = op.taps; e.stride = op.stride; e.wtaps = op.wtaps();
+                e.src = src; e.dst = dst; e.add_t0 = add_t0; e.ride = ride;
+                tab.push_back(e);
+            };
+            entry(v[0], 0, 2, 0, 1);      // x -> T1, ride -> T0
+            entry(v[2], 2, 1, 1, 0);      // T1 -> T0 (+ T0)
+            entry(v[3], 1, 2, 0, 0);      // T0 -> T1
+            entry(v[4], 2, 1, 1, 0);      // T1 -> T0 (+ T0: identity residual)
+            entry(v[5], 1, 3, 0, 0);      // T0 -> memory
+            if ((int)tab.size() != dad::CH_N) return fail(DAD_E_STATE, "parameter arena exhausted (level-0 chain images)");
+            m->chain = tab;
+            m->chain_C = cp.C; m->chain_last = cp.last;
+            if ((rc = repack_chain(m, st)) != DAD_OK) return rc;
+        }
     }
     if (m->training) {
         if (const char* why = training_refusal(*m)) return fail(DAD_E_INVALID, "training: %s", why);
@@ -909,7 +984,7 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     key.n_steps = n_steps; key.batch = batch; key.cond_per_row = cond_per_row;
     key.force_tile = m->force_tile;
     key.flags = (m->split_enabled ? 1 : 0) | (m->fuse_residual ? 2 : 0) | (m->xswz_enabled ? 4 : 0) |
-                (m->xcd_order ? 8 : 0) | (ccp ? 16 : 0) | (m->split_target << 8);
+                (m->xcd_order ? 8 : 0) | (ccp ? 16 : 0) | (m->chain_enabled ? 32 : 0) | (m->split_target << 8);
     key.row_offset = row_offset;
     if (proj) {
         uint64_t hsh = 1469598103934665603ull;            // FNV-1a over the per-step alphas
@@ -1042,6 +1117,7 @@ int dad_model_refresh_weights(dad_model* m, int32_t n, const char* const* keys, 
     if (const float* fb = has("final_conv.1.bias"))
         if ((rc = copy(m->d_final_b, fb, m->cfg.transition_dim)) != DAD_OK) return rc;
     if (tables_dirty && (rc = build_time_tables(m, st)) != DAD_OK) return rc;
+    if (!m->chain.empty() && (rc = repack_chain(m, st)) != DAD_OK) return rc;
     return DAD_OK;
 }
 
@@ -1352,6 +1428,13 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, u
 #ifdef DAD_STAMPS
 int dad_debug_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return DAD_OK; }
 #endif
+#ifdef DAD_CHAIN_STAMPS
+int dad_debug_chain_stamps(unsigned long long* host32) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(host32, HIP_SYMBOL(dad::g_chain_stamps), 32 * sizeof(unsigned long long)));
+    return DAD_OK;
+}
+#endif
 
 int dad_debug_set_tile(dad_model* m, int32_t cfg) {
     if (!m) return fail(DAD_E_INVALID, "null model");
@@ -1373,6 +1456,8 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value) {
     else if (key == "ccw_max_rows") m->ccw_max_rows = std::max(0, (int)value);
     else if (key == "ccw_min_blocks") m->ccw_min_blocks = std::max(1, (int)value);
     else if (key == "ccw_prefer16") m->ccw_prefer16 = value != 0;
+    else if (key == "chain") m->chain_enabled = value != 0;
+    else if (key == "chain_min_batch") m->chain_min_batch = std::max(1, (int)value);
     else return fail(DAD_E_INVALID, "unknown option '%s'", name);
     // every option changes which launches a captured loop holds, and not all of them are part of the
     // graph key: drop the cache (a replay may still be in flight: wait for the device first)

@@ -146,6 +146,11 @@ struct HostModel {
     int cc_max_rows = 512;                                     //   up to this many batch * horizon rows
     int ccw_max_rows = 128;                                    //   the same for nets whose plan needs conv_ccw.hpp (wide layers)
     int ccw_min_blocks = 256;                                  //   blocks a wide layer keeps when its K slices are fattened
+    bool chain_enabled = false;                                // level-0 encoder chain (conv_chain.hpp) for dim <= 128: opt-in
+                                                               //   ("chain" option / DAD_CHAIN=1) — measured 73-75 us against 68 us
+                                                               //   for the five launches it replaces
+    int chain_min_batch = 64;                                  //   from this batch on (one block per sample: below, the
+                                                               //   chip is mostly idle and the batch kernels' split-K wins)
     bool ccw_prefer16 = true;                                  //   two 16-row tiles instead of an LDS-short 32-row one
                                                                //   (measured crossover: batch 16 at H = 32)
     std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo
@@ -1067,6 +1072,29 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     return P;
 }
 
+// ------------------------------------------------------------------ level-0 chain (conv_chain.hpp)
+// downs.0.0 (first conv with the riding 1x1 residual conv, second conv), downs.0.1 (two convs) and the
+// down-sampling conv as ONE launch, one block per sample.  Architecture conditions (the batch threshold and
+// the per-call conditions — shared timestep, inference plan — are checked where it is launched):
+struct ChainPlan { bool ok = false; int last = -1; int C = 0; };
+inline ChainPlan chain_plan(const HostModel& m) {
+    ChainPlan P;
+    const dad_cfg& c = m.cfg;
+    const std::vector<ConvOp>& v = m.plan.convs;
+    if (m.precision != DAD_PREC_FP32 || c.kernel_size != 5 || c.horizon != 32 || c.n_levels < 2) return P;
+    const int C = c.channels[0];
+    if ((C != 32 && C != 64 && C != 128) || c.transition_dim > 16 || c.transition_dim == C || v.size() < 6) return P;
+    // the plan order of build_plan: conv0 (+ride), its stand-alone 1x1 form, conv1, conv0', conv1', down
+    if (!(v[0].ride && v[0].kind == CONV_K5 && v[0].src0 == -2 && v[0].cin1 == 0 && v[1].rider_of == 0 &&
+          v[2].kind == CONV_K5 && v[2].res == v[1].dst && v[3].kind == CONV_K5 && v[4].kind == CONV_K5 &&
+          v[4].res == v[3].src0 && v[5].kind == CONV_DOWN && v[5].src0 == v[4].dst))
+        return P;
+    for (int i : {0, 2, 3, 4, 5})
+        if (v[i].cout != C || v[i].kc != 16 || v[i].x3 || v[i].bdir) return P;
+    P.ok = true; P.last = 5; P.C = C;
+    return P;
+}
+
 // activations, then whichever scratch the batch uses: split-K slabs or the CC partial-sum slabs
 inline size_t workspace_bytes(const HostModel& m, int batch) {
     const CcPlan cc = cc_plan(m, batch);
@@ -1093,6 +1121,8 @@ inline size_t arena_bytes_needed(const HostModel& m) {
     add(T * std::max(1, m.plan.temb_width));
     add((size_t)4 * c.time_dim * c.dim); add(4 * c.time_dim);
     add((size_t)c.time_dim * 4 * c.time_dim); add(c.time_dim);
+    if (c.n_levels >= 2 && c.channels[0] <= 128)               // level-0 chain images (conv_chain.hpp)
+        for (int i = 0; i < 6 && i < (int)m.plan.convs.size(); ++i) add((size_t)m.plan.convs[i].cin_pad * 6 * m.plan.convs[i].M);
     if (m.training) {
         for (const HostModel::BwdConv& b : m.bconvs)
             for (int s = 0; s < b.n; ++s) add((size_t)b.op[s].cin_pad * b.op[s].wtaps() * b.op[s].M);

@@ -597,6 +597,39 @@ def test_assorted_architectures_match_oracle(arch, dev):
         assert err <= TOL_LOOP
 
 
+@pytest.mark.parametrize("arch", [(6, 32, (1, 2, 4), 70), (9, 64, (1, 2), 64), (6, 128, (1, 2, 4), 100), (16, 128, (1, 4), 65)],
+                         ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_B{a[3]}")
+def test_level0_chain_matches_oracle_and_the_separate_launches(arch, dev):
+    """csrc/conv_chain.hpp: downs.0.0 (+ riding 1x1 residual conv), downs.0.1 and the down-sampling conv as one
+    launch per sample (dim 32 / 64 / 128, batches of 64+): against the oracle, and against the same net with the
+    chain switched off (five separate launches) to fp32 rounding."""
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    from dynamics_aware_diffusion_amd.utils import synth
+    td, dim, mults, B = arch
+    state = synth.synth_unet_state(td, dim, mults, seed=23, affine_jitter=0.3)
+    w = {k: torch.from_numpy(v) for k, v in state.items()}
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet.load_state_dict(w)
+    diff = GaussianDiffusion(unet, 32, td - 1, 1, n_timesteps=30).to(dev)
+    x = torch.from_numpy(synth.normal_like(67, f"chain.{arch}", (B, 32, td)))
+    with torch.no_grad():
+        want = orc.unet_forward(w, x, torch.full((B,), 17, dtype=torch.long))
+    eng = diff._engine(dev)
+    try:
+        eng.debug_set_option("chain", 1)
+        got = diff.model(x.to(dev), 17).cpu().numpy()
+        again = diff.model(x.to(dev), 17).cpu().numpy()
+        eng.debug_set_option("chain", 0)
+        sep = diff.model(x.to(dev), 17).cpu().numpy()
+    finally:
+        eng.debug_set_option("chain", 0)               # (the default: opt-in)
+    assert np.array_equal(got, again)
+    assert max_abs(got, want.numpy()) <= TOL_STEP
+    assert max_abs(sep, want.numpy()) <= TOL_STEP
+    assert not np.array_equal(got, sep) or dim == 0        # (two different summation orders: the switch really switches)
+    assert max_abs(got, sep) <= 1e-5
+
+
 def test_unsupported_architectures_are_refused_with_a_message(dev):
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
     from dynamics_aware_diffusion_amd._engine import DadError
