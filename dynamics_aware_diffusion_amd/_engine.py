@@ -94,7 +94,8 @@ ABI = {
                                             C.POINTER(C.c_size_t)]),
     "dad_unet_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "dad_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "dad_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_void_p), C.c_int32,
                                     C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dad_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -417,21 +418,30 @@ class HipEngine:
                 saved.data_ptr(), saved.numel() * 4, self._stream()))
         return out, saved
 
-    def train_backward(self, x: torch.Tensor, d_out: torch.Tensor, saved: torch.Tensor, temb_width: int):
-        """(d_x, d_temb_rows, flat gradient buffer) for one batch (see dad_unet_backward)."""
+    def train_backward(self, x: torch.Tensor, d_out: torch.Tensor, saved: torch.Tensor, temb_width: int, shapes):
+        """(d_x, d_temb_rows, [one gradient tensor per entry of grad_layout(), shaped like ``shapes``]) for
+        one batch (see dad_unet_backward).  Separate tensors: autograd adopts them as ``.grad`` without copying."""
         B = self._traj(x)
         if self._traj(d_out, "d_out") != B:
             raise RuntimeError("d_out batch mismatch")
         sv, sc = C.c_size_t(), C.c_size_t()
         _check(self.lib, self.lib.dad_train_workspace_bytes(self._h, B, C.byref(sv), C.byref(sc)))
         scratch = torch.empty(max(sc.value, 4) // 4 + 4, dtype=torch.float32, device=self.device)
-        _, total = self.grad_layout()
-        grads = torch.empty(max(total, 4), dtype=torch.float32, device=self.device)
+        layout, _ = self.grad_layout()
+        if len(shapes) != len(layout):
+            raise RuntimeError(f"{len(shapes)} parameter shapes for {len(layout)} gradient tensors")
+        grads = []
+        for (key, _, numel), shape in zip(layout, shapes):
+            g = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+            if g.numel() != numel:
+                raise RuntimeError(f"gradient of {key}: shape {tuple(shape)} has {g.numel()} elements, expected {numel}")
+            grads.append(g)
+        ptrs = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         d_x = torch.empty_like(x)
         d_temb = torch.empty(B, temb_width, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.dad_unet_backward(
-                self._h, x.data_ptr(), d_out.data_ptr(), d_x.data_ptr(), d_temb.data_ptr(), grads.data_ptr(), B,
+                self._h, x.data_ptr(), d_out.data_ptr(), d_x.data_ptr(), d_temb.data_ptr(), ptrs, len(grads), B,
                 saved.data_ptr(), saved.numel() * 4, scratch.data_ptr(), scratch.numel() * 4, self._stream()))
         return d_x, d_temb, grads
 

@@ -1243,12 +1243,18 @@ int dad_unet_forward_train(dad_model* m, const float* x, const int32_t* row_inde
     return run_final(m, nullptr, x, 0, batch, nullptr, 1, out, (float*)saved, st, false, nullptr, true);
 }
 
-int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d_x, float* d_temb_rows, float* grads,
+int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d_x, float* d_temb_rows,
+                      float* const* grad_tensors, int32_t n_grad_tensors,
                       int32_t batch, void* saved_v, size_t saved_bytes, void* scratch_v, size_t scratch_bytes,
                       dad_stream_t stream) {
     int rc = check_train(m, batch);
     if (rc != DAD_OK) return rc;
-    if (!x || !d_out || !d_temb_rows || !grads || !saved_v || !scratch_v) return fail(DAD_E_INVALID, "null pointer");
+    if (!x || !d_out || !d_temb_rows || !grad_tensors || !saved_v || !scratch_v) return fail(DAD_E_INVALID, "null pointer");
+    if (n_grad_tensors != (int32_t)m->grad_slots.size())
+        return fail(DAD_E_INVALID, "%d gradient tensors passed, the model has %zu (dad_train_grad_count)", n_grad_tensors,
+                    m->grad_slots.size());
+    for (int32_t i = 0; i < n_grad_tensors; ++i)
+        if (!grad_tensors[i]) return fail(DAD_E_INVALID, "gradient tensor %d ('%s') is null", i, m->grad_slots[i].key.c_str());
     const int B = batch;
     const TrainScratch ts = train_scratch(*m, B);
     if (saved_bytes < train_saved_bytes(*m, B) || scratch_bytes < (size_t)ts.total * sizeof(float))
@@ -1274,7 +1280,7 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
     std::vector<int> owner(P.bufs.size(), -1);
     for (size_t i = 0; i < convs.size(); ++i) owner[convs[i].dst] = (int)i;
     bool dx_written = false;
-    auto G = [&](const std::string& key) -> float* { return grads + m->grad_at.at(key); };
+    auto G = [&](const std::string& key) -> float* { return grad_tensors[m->grad_index.at(key)]; };
 
     // y += x over n floats (n a multiple of 4), or y = x when y holds nothing yet
     auto accumulate = [&](float* y, const float* xs, long n, bool have) -> int {
@@ -1380,10 +1386,14 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
             gp.C = f.cout; gp.L = f.Lout; gp.cpg = f.cout / 8;
             hipLaunchKernelGGL(dad::gn_mish_bwd_kernel, dim3(B, 8), dim3(dad::GNB_THREADS), 0, st, gp);
             HIP_TRY(hipGetLastError());
-            // (the partial arrays are [B][C] with C = this conv's width)
-            if ((rc = col_sums(G(f.norm + ".weight"), gp.part_dgamma, f.cout)) != DAD_OK) return rc;
-            if ((rc = col_sums(G(f.norm + ".bias"), gp.part_dbeta, f.cout)) != DAD_OK) return rc;
-            if ((rc = col_sums(G(f.name + ".bias"), gp.part_dbias, f.cout)) != DAD_OK) return rc;
+            // (the partial arrays are [B][C] with C = this conv's width): the three reductions in one launch
+            {
+                dad::ColSums3 cs{};
+                cs.out[0] = G(f.norm + ".weight"); cs.out[1] = G(f.norm + ".bias"); cs.out[2] = G(f.name + ".bias");
+                cs.part[0] = gp.part_dgamma; cs.part[1] = gp.part_dbeta; cs.part[2] = gp.part_dbias;
+                hipLaunchKernelGGL(dad::col_sums3_kernel, dim3((unsigned)((f.cout + 31) / 32), 3), dim3(256), 0, st, cs, B, f.cout, f.cout);
+                HIP_TRY(hipGetLastError());
+            }
             dH = gp.dH;
         } else {
             if ((rc = bias_grad(G(f.name + ".bias"), dH, out_rows, f.cout)) != DAD_OK) return rc;

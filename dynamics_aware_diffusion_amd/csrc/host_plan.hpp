@@ -168,6 +168,7 @@ struct HostModel {
     std::vector<GradSlot> grad_slots;        // flat gradient buffer: reference state_dict keys, torch layouts
     long grad_numel = 0;
     std::map<std::string, long> grad_at;     // key -> offset
+    std::map<std::string, int> grad_index;   // key -> index into grad_slots
     int max_cout = 0;                        // widest conv output (per-sample partial sums)
     int max_bwd_m = 0;                       // widest data-gradient launch (zero bias row)
 };
@@ -424,9 +425,10 @@ inline ConvOp make_bwd_op(const ConvOp& f, const char* tag, ConvKind kind, int t
 inline int build_backward_plan(HostModel* m) {
     const std::vector<ConvOp>& convs = m->tplan.convs;
     m->bconvs.assign(convs.size(), HostModel::BwdConv());
-    m->grad_slots.clear(); m->grad_at.clear(); m->grad_numel = 0;
+    m->grad_slots.clear(); m->grad_at.clear(); m->grad_index.clear(); m->grad_numel = 0;
     m->max_cout = m->cfg.dim; m->max_bwd_m = m->cfg.dim;
     auto slot = [&](const std::string& key, long numel) {
+        m->grad_index[key] = (int)m->grad_slots.size();
         m->grad_slots.push_back({key, m->grad_numel, numel});
         m->grad_at[key] = m->grad_numel;
         m->grad_numel += (numel + 3) / 4 * 4;

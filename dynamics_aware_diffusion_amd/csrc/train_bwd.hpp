@@ -272,6 +272,35 @@ __global__ __launch_bounds__(256) void col_sums_kernel(float* out, const float* 
     }
 }
 
+// the same for three [B][C] arrays at once (blockIdx.y picks one): d gamma, d beta, d bias of one conv
+struct ColSums3 { float* out[3]; const float* part[3]; };
+__global__ __launch_bounds__(256) void col_sums3_kernel(const ColSums3 a, int B, int stride, int C) {
+    __shared__ float red[8][33];
+    const float* part = blockIdx.y == 0 ? a.part[0] : (blockIdx.y == 1 ? a.part[1] : a.part[2]);
+    float* out = blockIdx.y == 0 ? a.out[0] : (blockIdx.y == 1 ? a.out[1] : a.out[2]);
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        int b = rg;
+        for (; b + 24 < B; b += 32) {
+            a0 += part[(long)b * stride + c];
+            a1 += part[(long)(b + 8) * stride + c];
+            a2 += part[(long)(b + 16) * stride + c];
+            a3 += part[(long)(b + 24) * stride + c];
+        }
+        for (; b < B; b += 8) a0 += part[(long)b * stride + c];
+    }
+    red[rg][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float v = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += red[k][col];
+        out[c] = v;
+    }
+}
+
 // --------------------------------------------------------------------- GroupNorm + Mish backward
 // Forward (temporal_unet.py:57-76,106-122):  h = conv(x) + bias;  xh = (h - mean) * rstd;  u = gamma xh + beta;
 // a = Mish(u) (+ temb[b, c]).  Given dA:

@@ -142,9 +142,9 @@ int dad_unet_forward_rows(dad_model* m, const float* x, const int32_t* t_rows, f
  * and the backward returns the gradient with respect to them.  fp32 only; no optimiser, no EMA.
  *
  * dad_model_set_training(m, 1) must precede dad_model_finalize (the extra weight images are packed
- * there).  Gradients come back in ONE flat fp32 device buffer; dad_train_grad_info enumerates
- * (reference state_dict key without "model.", offset in floats, element count) — every tensor in the
- * reference's own layout (Conv1d (out, in, k); ConvTranspose1d (in, out, k)).  The time-MLP tensors are
+ * there).  dad_train_grad_info enumerates the gradient tensors (reference state_dict key without "model.",
+ * element count; `offset` is their position in a packed buffer for callers that want one) — every tensor in
+ * the reference's own layout (Conv1d (out, in, k); ConvTranspose1d (in, out, k)).  The time-MLP tensors are
  * not in the list. */
 int dad_model_set_training(dad_model* m, int32_t on);
 /* Replaces: nothing in the reference (its modules ARE the parameters); here the engine holds packed copies,
@@ -168,11 +168,13 @@ int dad_unet_forward_train(dad_model* m, const float* x, const int32_t* row_inde
                            float* out, int32_t batch, void* saved, size_t saved_bytes, dad_stream_t stream);
 /* Replaces: autograd's walk from d loss / d eps back through the denoiser.  d_out: (B, H, td);
  * d_x (optional): (B, H, td) gradient w.r.t. the noisy trajectory; d_temb_rows: (B, temb_width), fully
- * overwritten; grads: the flat buffer of dad_train_grad_count floats, fully overwritten (each call
- * computes the gradient of ONE batch; accumulation over micro-batches is the caller's add). */
+ * overwritten; grad_tensors: one device tensor per entry of dad_train_grad_info, in that order, each of that
+ * entry's element count and fully overwritten (separate tensors so that autograd can adopt them as .grad
+ * without a copy; each call computes the gradient of ONE batch: accumulation over micro-batches is the
+ * caller's add). */
 int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d_x, float* d_temb_rows,
-                      float* grads, int32_t batch, void* saved, size_t saved_bytes, void* scratch,
-                      size_t scratch_bytes, dad_stream_t stream);
+                      float* const* grad_tensors, int32_t n_grad_tensors, int32_t batch, void* saved,
+                      size_t saved_bytes, void* scratch, size_t scratch_bytes, dad_stream_t stream);
 
 /* Arguments of one reverse step beyond (x, t). All pointers may be NULL unless noted. */
 typedef struct dad_step_args {
