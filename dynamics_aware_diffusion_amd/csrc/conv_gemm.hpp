@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     constexpr int NSUB = KC / KG;                // packed granules per chunk
     static_assert(KC % KU == 0 && G % SK == 0 && GW >= 1, "K chunk must split evenly over the SK waves");
     static_assert(!BDIR || (BN == 32 && SK == 1 && !RAGGED && KC >= 16), "direct-B tiles");
-    static_assert(!RES || (!X3 && !BDIR && TAPS == 5 && STRIDE == 1), "the residual ride exists for fp32 5-tap convs");
+    static_assert(!RES || (!X3 && !BDIR && (TAPS & 1) == 1 && TAPS >= 3 && STRIDE == 1), "the residual ride exists for fp32 stride-1 convs of the net's kernel size");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Vector accesses go through these views with an index in vector units: every offset below

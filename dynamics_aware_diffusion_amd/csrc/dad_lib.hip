@@ -154,13 +154,15 @@ void reg_kernel(KernTable& t) {
     constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR, T::BN);
     t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, false, RES)] =
         dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR, RES>;
-    if constexpr (!BDIR && STRIDE == 1 && (TAPS == 5 || TAPS == 1))    // general staging path
+    if constexpr (!BDIR && STRIDE == 1 && (TAPS & 1) == 1)             // general staging path
         t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, true, RES)] =
             dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, true, X3, BDIR, RES>;
 }
 template <int CFG>
 void reg_tile(KernTable& t) {
     reg_kernel<CFG, 5, 1, false, false, false>(t);
+    reg_kernel<CFG, 3, 1, false, false, false>(t);      // TemporalUnet(kernel_size=3 / 7) (temporal_unet.py:139): fp32 only
+    reg_kernel<CFG, 7, 1, false, false, false>(t);
     reg_kernel<CFG, 3, 2, false, false, false>(t);
     if constexpr (Tile<CFG>::KC >= 16)                      // backward of Upsample1d: 5-tap stride-2 conv
         reg_kernel<CFG, 5, 2, false, false, false>(t);
@@ -168,6 +170,8 @@ void reg_tile(KernTable& t) {
     reg_kernel<CFG, 1, 1, false, false, false>(t);
     if constexpr (Tile<CFG>::KC >= 16) {
         reg_kernel<CFG, 5, 1, false, false, true>(t);      // + the riding 1x1 residual conv
+        reg_kernel<CFG, 3, 1, false, false, true>(t);
+        reg_kernel<CFG, 7, 1, false, false, true>(t);
         reg_kernel<CFG, 5, 1, true, false, false>(t);      // split-f16 variants (16-channel granules)
         reg_kernel<CFG, 3, 2, true, false, false>(t);
         reg_kernel<CFG, 2, 1, true, false, false>(t);
@@ -175,6 +179,10 @@ void reg_tile(KernTable& t) {
     } else {                                               // wide tile: direct-B kernels of the GroupNorm'd 5-tap convs
         reg_kernel<CFG, 5, 1, true, true, false>(t);
         reg_kernel<CFG, 5, 1, false, true, false>(t);
+        reg_kernel<CFG, 3, 1, true, true, false>(t);       // kernel_size 3 / 7 (an LDS weight stage of 7 taps x 256 rows
+        reg_kernel<CFG, 3, 1, false, true, false>(t);      //   would not fit twice)
+        reg_kernel<CFG, 7, 1, true, true, false>(t);
+        reg_kernel<CFG, 7, 1, false, true, false>(t);
     }
 }
 const KernTable& kernel_table() {
@@ -255,6 +263,7 @@ int configure_kernels() {
     HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
@@ -1318,6 +1327,7 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
             case 3: hipLaunchKernelGGL(dad::conv_wgrad<3>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
             case 4: hipLaunchKernelGGL(dad::conv_wgrad<4>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
             case 5: hipLaunchKernelGGL(dad::conv_wgrad<5>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
+            case 7: hipLaunchKernelGGL(dad::conv_wgrad<7>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
             default: return fail(DAD_E_INVALID, "wgrad: %d taps", taps);
         }
         HIP_TRY(hipGetLastError());

@@ -179,7 +179,8 @@ inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // ----------------------------------------------------------------------------- validation
 inline int check_cfg(const dad_cfg* cfg) {
     if (!cfg) return fail(DAD_E_INVALID, "null argument");
-    if (cfg->kernel_size != 5) return fail(DAD_E_INVALID, "kernel_size %d unsupported (5 only)", cfg->kernel_size);
+    if (cfg->kernel_size != 3 && cfg->kernel_size != 5 && cfg->kernel_size != 7)
+        return fail(DAD_E_INVALID, "kernel_size %d unsupported (3, 5 or 7)", cfg->kernel_size);
     if (cfg->n_levels < 1 || cfg->n_levels > DAD_MAX_LEVELS)
         return fail(DAD_E_INVALID, "n_levels %d out of range", cfg->n_levels);
     if (cfg->transition_dim < 1 || cfg->dim < 4 || (cfg->dim & 1) || cfg->time_dim < 1)
@@ -228,7 +229,7 @@ inline void expect(HostModel* m, const std::string& key, std::vector<int64_t> sh
 // Which kernel family a conv belongs to — a function of the architecture and the precision only
 // (so workspace sizes do not depend on whether weights have been loaded yet):
 //   bdir  wide-group layers (op.kc == 8) use the direct-B kernel in either arithmetic: 16-channel
-//         granules, whole 32-channel chunks, 5-tap stride-1 only (else the LDS-staged wide kernel)
+//         granules, whole 32-channel chunks, the net's k-tap stride-1 convs only (else the LDS-staged wide kernel)
 //   ride  the weight image carries the block's 1x1 residual conv as a sixth tap (fp32, LDS-staged)
 //   x3    split-f16 operands where the kernels exist for every tile this layer may get: 16-channel
 //         granules, and for the strided / transposed convs (no general staging path) whole
@@ -242,7 +243,7 @@ inline void decide_kernel_families(HostModel* m) {
         op.ride = !op.rname.empty() && !op.bdir && m->precision == DAD_PREC_FP32;
         op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
                 (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
-                 (op.kind == CONV_K5 || op.kind == CONV_1X1 ||
+                 ((op.kind == CONV_K5 && op.taps == 5) || op.kind == CONV_1X1 ||
                   ((op.cin0 & 63) == 0 && (cin_all & 63) == 0)));
     }
 }
@@ -480,11 +481,25 @@ inline const char* training_refusal(const HostModel& m) {
     return nullptr;
 }
 
+inline bool tile_valid(const ConvOp& op, int cfg);
+// An architecture some layer of which has no conv-GEMM tile is refused when the model is created, not at
+// its first launch (validity of a tile does not depend on the batch).
+inline int check_tiles(const HostModel& m) {
+    for (const ConvOp& op : m.plan.convs) {
+        bool any = false;
+        for (int cfg = 0; cfg < kNumTiles && !any; ++cfg) any = tile_valid(op, cfg);
+        if (!any)
+            return fail(DAD_E_INVALID, "no tile configuration for %s (M=%d, C/8=%d, L=%d, %d taps)",
+                        op.name.c_str(), op.M, op.cout / 8, op.Lout, op.taps);
+    }
+    return DAD_OK;
+}
 inline int build_plan(HostModel* m) {
     m->expected.clear();
     int rc = build_plan_into(m, m->plan, false);
     if (rc == DAD_OK) rc = build_plan_into(m, m->tplan, true);
     if (rc == DAD_OK) decide_kernel_families(m);
+    if (rc == DAD_OK) rc = check_tiles(*m);
     if (rc == DAD_OK) rc = build_backward_plan(m);
     return rc;
 }
@@ -826,17 +841,17 @@ inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g)
     g.kc = eff_kc(t.KC, t.BM, op.taps, t.SK, op.x3, op.bdir, t.BN);
     const int cin = op.cin0 + op.cin1;
     g.ragged = (op.cin0 & 3) != 0 || (op.cin1 & 3) != 0 || op.cin0 % g.kc != 0 || cin % g.kc != 0;
-    if (g.ragged && !(op.stride == 1 && (op.taps == 5 || op.taps == 1)))
+    if (g.ragged && !(op.stride == 1 && (op.taps & 1) == 1))
         return fail(DAD_E_INVALID, "channel count %d+%d needs the general staging path, which exists "
-                    "for stride-1 5-tap and 1x1 convs only", op.cin0, op.cin1);
+                    "for stride-1 k-tap and 1x1 convs only", op.cin0, op.cin1);
     if (op.bdir && g.ragged)
         return fail(DAD_E_INVALID, "the direct-B kernel needs whole 32-channel chunks (%d+%d)", op.cin0, op.cin1);
-    if (op.bdir && !(t.KC == 8 && op.taps == 5 && op.stride == 1))
+    if (op.bdir && !(t.KC == 8 && op.kind == CONV_K5 && op.stride == 1))
         return fail(DAD_E_INVALID, "no direct-B kernel for tile %d taps=%d stride=%d", g.cfg, op.taps, op.stride);
     if (op.x3 && !op.bdir && t.KC < 16)
         return fail(DAD_E_INVALID, "no split-f16 kernel for tile %d taps=%d stride=%d", g.cfg, op.taps, op.stride);
     g.fused = fused_at(m, op, batch);
-    if (g.fused && (op.x3 || op.bdir || op.taps != 5 || op.stride != 1))
+    if (g.fused && (op.x3 || op.bdir || op.kind != CONV_K5 || op.stride != 1))
         return fail(DAD_E_INVALID, "no fused-residual kernel for %s on tile %d", op.name.c_str(), g.cfg);
     if (op.cin_pad % g.kc != 0 && !g.ragged)
         return fail(DAD_E_INVALID, "%s: padded channel count %d is not a multiple of the K chunk %d",
@@ -921,9 +936,9 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     CcPlan P;
     const dad_cfg& c = m.cfg;
     const std::vector<ConvOp>& convs = m.plan.convs;
-    if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 32 ||
+    if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 32 || c.kernel_size != 5 ||
         (long)batch * c.horizon > m.cc_max_rows)
-        return refuse(P, "disabled, split-f16 arithmetic, horizon > 32 or more than cc_max_rows rows");
+        return refuse(P, "disabled, split-f16 arithmetic, horizon > 32, kernel_size != 5 or more than cc_max_rows rows");
     for (const ConvOp& op : convs)      // weight images in 16-channel granules only
         if ((op.kc != 16 && !op.bdir) || op.cat0 >= 0 || op.x3 || (!op.rname.empty() && !op.ride)) return refuse(P, "a weight image not in 16-channel granules, or an identity residual over a concat");
     P.ops.resize(convs.size());

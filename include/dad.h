@@ -64,7 +64,7 @@ typedef struct dad_cfg {
     int32_t time_dim;                 /* time-embedding width (reference: == dim)         */
     int32_t n_levels;                 /* len(dim_mults)                                   */
     int32_t channels[DAD_MAX_LEVELS]; /* dim * dim_mults[i] per level                     */
-    int32_t kernel_size;              /* 5 (only value supported)                         */
+    int32_t kernel_size;              /* 3, 5 or 7 (temporal_unet.py:139; 5 in every recipe)  */
     int32_t horizon;                  /* planning horizon H: a power of two with
                                          H / 2^(n_levels-1) >= 4 (the deepest level keeps at
                                          least 4 positions; else DAD_E_INVALID)              */

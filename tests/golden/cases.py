@@ -94,6 +94,9 @@ NETS = {
     "pointmaze_j": (4, 2, 128, (1, 2, 4), 100, 8, 0.25),
     "halfcheetah_j": (17, 6, 256, (1, 4, 8), 1000, 8, 0.25),
     "door_j": (39, 28, 256, (1, 2, 4, 8), 1000, 8, 0.25),
+    # TemporalUnet(kernel_size=3 / 7) (temporal_unet.py:139; see KERNEL_SIZES)
+    "tiny_k3": (4, 2, 32, (1, 2, 4), 20, 9, 0.25),
+    "tiny_k7": (5, 3, 64, (1, 2), 20, 10, 0.25),
 }
 
 # (case, net, B, t)  — single U-Net forward
@@ -103,6 +106,8 @@ FORWARD_CASES = [
     ("fwd_pointmaze", "pointmaze_j", 2, 63),
     ("fwd_halfcheetah", "halfcheetah_j", 2, 500),
     ("fwd_door", "door_j", 2, 999),
+    ("fwd_tiny_k3", "tiny_k3", 3, 11),
+    ("fwd_tiny_k7", "tiny_k7", 5, 2),
 ]
 
 # (case, net, T_train, n_sample_steps, B, conditioned, schedule)
@@ -159,6 +164,7 @@ VALUE_HIDDEN = 16
 
 
 TIME_DIMS = {"tiny_td64": 64}        # nets whose time embedding is wider than `dim`
+KERNEL_SIZES = {"tiny_k3": 3, "tiny_k7": 7}      # nets whose Conv1dBlocks are not 5 taps wide
 
 
 # Training objective, forward only (diffusion.py:253-290; losses/__init__.py:37-186).
@@ -180,6 +186,8 @@ GRAD_CASES = [
     ("grads_tiny", "tiny", 20, 6, "l2", True, False),
     ("grads_tiny4", "tiny4", 20, 5, "l1", True, True),
     ("grads_pointmaze_B9", "pointmaze", 100, 9, "l2", True, False),
+    ("grads_tiny_k3", "tiny_k3", 20, 5, "l2", True, False),
+    ("grads_tiny_k7", "tiny_k7", 20, 4, "l2", True, True),
 ]
 GRAD_SAMPLE = 2048
 
@@ -206,6 +214,10 @@ def net_time_dim(net: str):
     return TIME_DIMS.get(net)
 
 
+def net_kernel_size(net: str) -> int:
+    return KERNEL_SIZES.get(net, 5)
+
+
 def net_dims(net: str):
     od, ad, dim, mults, T, seed, jitter = NETS[net]
     return od, ad, od + ad, dim, mults
@@ -214,7 +226,7 @@ def net_dims(net: str):
 def net_weights(net: str) -> "OrderedDict[str, np.ndarray]":
     od, ad, dim, mults, T, seed, jitter = NETS[net]
     return synth.synth_unet_state(od + ad, dim, mults, seed=seed, affine_jitter=jitter,
-                                  time_dim=net_time_dim(net))
+                                  time_dim=net_time_dim(net), kernel_size=net_kernel_size(net))
 
 
 def forward_input(case: str, net: str, B: int) -> np.ndarray:

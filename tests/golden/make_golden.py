@@ -89,7 +89,8 @@ def injected_noise(stack: np.ndarray):
 
 def build_reference(net: str, T: int, schedule: str = "cosine", **diffusion_kw):
     od, ad, td, dim, mults = cases.net_dims(net)
-    unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults), time_dim=cases.net_time_dim(net))
+    unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults), time_dim=cases.net_time_dim(net),
+                                 kernel_size=cases.net_kernel_size(net))
     load_into(unet, cases.net_weights(net))
     diff = GaussianDiffusion(unet, cases.H, od, ad, n_timesteps=T, beta_schedule=schedule,
                              **diffusion_kw)
@@ -150,9 +151,12 @@ def gen_forward(only_small: bool = False):
     for case, net, B, t in cases.FORWARD_CASES:
         if only_small and net.startswith(("halfcheetah", "door")):
             continue
+        if CASE_FILTER and case not in CASE_FILTER:
+            continue
         print(f"  forward {case} ...")
         od, ad, td, dim, mults = cases.net_dims(net)
-        unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults)).eval()
+        ks = cases.net_kernel_size(net)
+        unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults), kernel_size=ks).eval()
         load_into(unet, cases.net_weights(net))
         x = torch.from_numpy(cases.forward_input(case, net, B))
         tt = torch.full((B,), t, dtype=torch.long)
@@ -179,7 +183,7 @@ def gen_forward(only_small: bool = False):
             else:
                 y = unet(x, tt)
             # fp64 truth with the reference modules themselves (sinusoid stays fp32)
-            u64 = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults)).eval()
+            u64 = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults), kernel_size=ks).eval()
             load_into(u64, cases.net_weights(net))
             u64 = u64.double()
             pos = u64.time_mlp[0]
@@ -342,6 +346,8 @@ def gen_grads():
     """The reference's own backward pass (utils/training.py:152-156): GaussianDiffusion.loss arithmetic
     (diffusion.py:253-290) on injected draws, loss.backward(), every parameter gradient and d loss / d x_t."""
     for case, net, T, B, loss_type, pred_eps, weighted in cases.GRAD_CASES:
+        if CASE_FILTER and case not in CASE_FILTER:
+            continue
         print(f"  grads {case} ...", flush=True)
         diff = build_reference(net, T, loss_type=loss_type, predict_epsilon=pred_eps).train()
         x0, t, noise, w = cases.train_inputs(case, net, T, B, weighted)
@@ -514,6 +520,8 @@ def gen_keys():
     print("  wrote state_dict_keys.json")
 
 
+CASE_FILTER: set = set()          # --cases: regenerate only these fixtures of the forward / grads sections
+
 SECTIONS = {
     "keys": gen_keys,
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
@@ -526,7 +534,9 @@ SECTIONS = {
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--cases", default="", help="comma-separated fixture names (forward / grads sections)")
     args = ap.parse_args()
+    CASE_FILTER.update(c for c in args.cases.split(",") if c)
     torch.manual_seed(0)
     for name, fn in SECTIONS.items():
         if args.only and name not in args.only.split(","):

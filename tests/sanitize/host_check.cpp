@@ -29,6 +29,7 @@ struct Arch {
     int td, dim, time_dim, horizon;
     std::vector<int> mults;
     bool pack;      // also load synthetic weights and build the packed images
+    int ks = 5;     // TemporalUnet(kernel_size): 3, 5 or 7
 };
 
 static float synth(uint64_t& state) {       // cheap deterministic values in (-1, 1)
@@ -61,7 +62,7 @@ static void check_arch(const Arch& a, int precision) {
     c.transition_dim = a.td; c.dim = a.dim; c.time_dim = a.time_dim;
     c.n_levels = (int)a.mults.size();
     for (size_t i = 0; i < a.mults.size(); ++i) c.channels[i] = a.dim * a.mults[i];
-    c.kernel_size = 5; c.horizon = a.horizon; c.n_timesteps = 20;
+    c.kernel_size = a.ks; c.horizon = a.horizon; c.n_timesteps = 20;
     c.predict_epsilon = c.clip_denoised = 1;
     m.precision = precision;               // (build_plan decides the kernel families from it)
     int rc = check_cfg(&c);
@@ -205,7 +206,7 @@ static void check_arch(const Arch& a, int precision) {
                         // the stage was sized with kXSwzPad floats of slack for shifts of at most 15 slots
                         CHECK(15 * 4 <= dad::kXSwzPad, "slot shift slack");
                     }
-                    if (g.fused) CHECK(op.ride && op.taps == 5 && op.stride == 1 && !op.x3 && !op.bdir, "%s: ride", op.name.c_str());
+                    if (g.fused) CHECK(op.ride && op.kind == CONV_K5 && (op.taps & 1) && op.stride == 1 && !op.x3 && !op.bdir, "%s: ride", op.name.c_str());
                 }
             }
         }
@@ -377,6 +378,12 @@ int main(int argc, char** argv) {
         {"h64", 23, 64, 64, 64, {1, 1, 2}, true},
         {"h128", 6, 128, 128, 128, {1, 2, 4}, true},
         {"h128w", 23, 256, 256, 128, {1, 4, 8}, false},
+        {"pointmaze_k3", 6, 128, 128, 32, {1, 2, 4}, true, 3},
+        {"tiny_k7", 8, 64, 64, 32, {1, 2}, true, 7},
+        {"wide_k3", 23, 256, 256, 32, {1, 4, 8}, !quick, 3},
+        {"wide_k7", 9, 256, 256, 16, {1, 8}, false, 7},
+        {"h128_k7", 6, 128, 128, 128, {1, 2}, true, 7},
+        {"shrink_k7", 5, 32, 32, 32, {1, 4, 2}, true, 7},
     };
     // the fuzz generator's space (tests/fuzz_parity.py), deterministic sweep
     std::mt19937 rng(7);
@@ -393,7 +400,7 @@ int main(int argc, char** argv) {
         const int td = 2 + (int)(rng() % 23);
         if (mx * dim > 2048) continue;
         names.push_back("fuzz" + std::to_string(it));
-        archs.push_back({names.back().c_str(), td, dim, dim, H, mults, mx * dim <= 512});
+        archs.push_back({names.back().c_str(), td, dim, dim, H, mults, mx * dim <= 512, it % 4 == 3 ? pick({3, 7}) : 5});
     }
     for (const Arch& a : archs)
         for (int prec : {DAD_PREC_FP32, DAD_PREC_F16X3}) check_arch(a, prec);

@@ -73,7 +73,7 @@ def test_grid_split_k_is_exact_to_rounding_and_deterministic(dev):
 
 def test_wide_group_tiles_on_big_architectures(dev):
     """HalfCheetah / Door exercise the 128- and 256-channel GroupNorm tiles (cfg 2 and 3)."""
-    for name, net, B, t in cases.FORWARD_CASES[3:]:
+    for name, net, B, t in cases.FORWARD_CASES[3:5]:
         g = golden(name)
         diff = build(net, cases.NETS[net][4], "cosine", dev)
         x = torch.from_numpy(cases.forward_input(name, net, B)).to(dev)
@@ -555,15 +555,22 @@ def test_graph_replay_with_inkernel_noise(dev):
     (6, 128, (1, 2, 4), 128, 9),       # tiles <32,128> on level 0, batch 1 and 9
     (23, 256, (1, 4, 8), 128, 3),      # the same on the HalfCheetah widths (64-channel groups at L = 64: <128,64>)
     (14, 64, (1, 2, 4, 8), 64, 5),     # horizon 64 on four levels
-], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}")
+    (6, 128, (1, 2, 4), 32, 9, 3),     # TemporalUnet(kernel_size=3) (temporal_unet.py:139) on the PointMaze widths: split-K batch
+    (6, 128, (1, 2, 4), 32, 130, 3),   #   ... and a batch with the 1x1 residual conv riding as the fourth tap
+    (6, 64, (1, 2, 4), 32, 70, 7),     # kernel_size=7: three halo rows per sample side, ride as the eighth tap
+    (11, 32, (1, 2), 16, 1, 7),        #   ... batch 1 (the small-batch kernels are 5-tap only: batch kernels + split-K)
+    (23, 256, (1, 4, 8), 32, 4, 3),    # kernel_size=3 on the HalfCheetah widths (LDS-staged <256,32> tile at 2048 channels)
+    (5, 32, (1, 4, 2), 32, 3, 7),      # kernel_size=7 with an identity residual over the concat
+], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}" + (f"_k{a[5]}" if len(a) > 5 else ""))
 def test_assorted_architectures_match_oracle(arch, dev):
     """Shapes outside the three BASELINE architectures, against the oracle on seeded inputs."""
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
     from dynamics_aware_diffusion_amd.utils import synth
-    td, dim, mults, H, B = arch
-    state = synth.synth_unet_state(td, dim, mults, seed=17, affine_jitter=0.3)
+    td, dim, mults, H, B = arch[:5]
+    ks = arch[5] if len(arch) > 5 else 5
+    state = synth.synth_unet_state(td, dim, mults, seed=17, affine_jitter=0.3, kernel_size=ks)
     w = {k: torch.from_numpy(v) for k, v in state.items()}
-    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults, kernel_size=ks)
     unet.load_state_dict(w)
     diff = GaussianDiffusion(unet, H, td - 1, 1, n_timesteps=30).to(dev)
     x = torch.from_numpy(synth.normal_like(66, f"arch.{arch}", (B, H, td)))
@@ -630,12 +637,53 @@ def test_level0_chain_matches_oracle_and_the_separate_launches(arch, dev):
     assert max_abs(got, sep) <= 1e-5
 
 
+def test_per_row_timesteps_near_the_end_of_the_schedule_on_a_wide_net(dev):
+    """`dad_unet_forward_rows` indexes the per-timestep table with t_row[b] only where a conv HAS a
+    time embedding (the second conv of a block, the resampling and 1x1 convs fall back to the bias row and must
+    not be offset by t * temb_width): rows at t = T-1 on HalfCheetah's widths (temb_width 10 752, T = 1000), a
+    NaN-poisoned neighbourhood would show as NaN."""
+    from dynamics_aware_diffusion_amd.utils import synth
+    diff = build("halfcheetah", 1000, "cosine", dev)
+    B = 5
+    x = torch.from_numpy(synth.normal_like(84, "rows.hc", (B, 32, diff.transition_dim)))
+    t = torch.tensor([999, 0, 998, 500, 999], dtype=torch.long)
+    with torch.no_grad():
+        want = orc.unet_forward(net_weights_torch("halfcheetah"), x, t).numpy()
+        got = diff.model(x.to(dev), t.to(dev)).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert max_abs(got, want) <= TOL_STEP
+
+
+def test_projector_refuses_a_batch_of_another_shape(dev):
+    """the projection kernels derive D from the batch's horizon; a batch whose horizon or
+    transition width differs from what P was built for must raise (the reference: matmul shape error,
+    guides/policies.py:451, losses/__init__.py:181), not read P out of bounds."""
+    from dynamics_aware_diffusion_amd._engine import ProjectionState
+    from dynamics_aware_diffusion_amd.dynamics import ProjectionMatrixBuilder, double_integrator
+    import contextlib
+    import io
+    A, Bm = double_integrator(0.1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        P = ProjectionMatrixBuilder(A, Bm, 4, 2).get_projection_matrix(32)
+    n = cases.NormalizerStub(4, 2)
+    st = ProjectionState(P, n.obs_mean, n.obs_std, n.action_mean, n.action_std, 4, 4, 2, dev)
+    st.apply(torch.zeros(3, 32, 6, device=dev), 0.5)                       # the shape it was built for
+    for shape in ((3, 16, 6), (3, 32, 7), (3, 64, 6)):
+        with pytest.raises(RuntimeError):
+            st.apply(torch.zeros(*shape, device=dev), 0.5)
+        with pytest.raises(RuntimeError):
+            st.violation(torch.zeros(*shape, device=dev))
+    with pytest.raises(RuntimeError):
+        st.apply(torch.zeros(3, 32, 6), 0.5)                               # CPU tensor
+
+
 def test_unsupported_architectures_are_refused_with_a_message(dev):
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
     from dynamics_aware_diffusion_amd._engine import DadError
     for kwargs, H in ((dict(dim=32, dim_mults=(1, 2, 4, 8)), 16),     # 16 / 8 = 2 < 4
                       (dict(dim=48, dim_mults=(1, 2)), 32),           # C/8 = 6 not a power of two
-                      (dict(dim=32, dim_mults=(1, 2), kernel_size=3), 32)):
+                      (dict(dim=32, dim_mults=(1, 2), kernel_size=4), 32),   # even kernel: the reference's padding k//2 changes the length
+                      (dict(dim=32, dim_mults=(1, 2), kernel_size=9), 32)):
         unet = TemporalUnet(6, **kwargs)
         diff = GaussianDiffusion(unet, H, 4, 2, n_timesteps=10).to(dev)
         with pytest.raises(DadError):

@@ -39,7 +39,8 @@ def build(net: str, T: int, schedule: str, dev, **diffusion_kw):
     if key in _MODELS:
         return _MODELS[key]
     od, ad, td, dim, mults = cases.net_dims(net)
-    unet = TemporalUnet(td, dim=dim, dim_mults=mults, time_dim=cases.net_time_dim(net))
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults, time_dim=cases.net_time_dim(net),
+                        kernel_size=cases.net_kernel_size(net))
     sd = {k: torch.from_numpy(v) for k, v in cases.net_weights(net).items()}
     missing, unexpected = unet.load_state_dict(sd, strict=True)
     diff = GaussianDiffusion(unet, cases.H, od, ad, n_timesteps=T, beta_schedule=schedule,

@@ -205,7 +205,10 @@ def test_sgd_steps_track_the_oracle_without_leaving_the_device(dev):
     (9, 128, (1, 8, 4), 16, 4),        # 1024 channels (128-channel groups, <128,64>), shrinking tail 1024 -> 512 is refused below
     (7, 64, (1, 2, 4, 8), 32, 2),      # four levels, L down to 4: every down / up-sampling conv shape
     (6, 128, (1, 2), 128, 2),          # horizon 128: the <32,128> tiles in the training forward and the data gradients
-], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}")
+    (6, 64, (1, 2, 4), 32, 5, 3),      # TemporalUnet(kernel_size=3) (temporal_unet.py:139): 3-tap forward, flipped 3-tap data gradient, wgrad<3>
+    (7, 32, (1, 4), 16, 3, 7),         # kernel_size=7: halo of three rows per sample side, wgrad<7>
+    (5, 256, (1, 8), 8, 2, 3),         # kernel_size=3 on 2048 channels: the LDS-staged <256,32> tile (the direct-B kernel is 5-tap only)
+], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}" + (f"_k{a[5]}" if len(a) > 5 else ""))
 def test_gradients_on_other_architectures_vs_oracle(arch, dev):
     """The backward pass beyond the fixture nets: wide GroupNorm groups (the direct-B forward tile keeps the
     pre-activation and statistics too), four levels, horizon 128 — every parameter gradient and dL/dx against
@@ -214,11 +217,12 @@ def test_gradients_on_other_architectures_vs_oracle(arch, dev):
     from dynamics_aware_diffusion_amd._engine import DadError
     from dynamics_aware_diffusion_amd.utils import synth
     from oracle import denoiser as orc
-    td, dim, mults, H, B = arch
+    td, dim, mults, H, B = arch[:5]
+    ks = arch[5] if len(arch) > 5 else 5
     T = 20
-    state = synth.synth_unet_state(td, dim, mults, seed=19, affine_jitter=0.3)
+    state = synth.synth_unet_state(td, dim, mults, seed=19, affine_jitter=0.3, kernel_size=ks)
     w = {k: torch.from_numpy(v) for k, v in state.items()}
-    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults, kernel_size=ks)
     unet.load_state_dict(w)
     diff = GaussianDiffusion(unet, H, td - 1, 1, n_timesteps=T).to(dev)
     x0 = torch.from_numpy(np.clip(synth.normal_like(20, f"garch.x.{arch}", (B, H, td)) * 0.5, -1, 1).astype(np.float32))
