@@ -496,10 +496,25 @@ def main() -> None:
             if rep:
                 fwd.append(t1 - t0)
                 bwd.append(t2 - t1)
+        # steady state: steps issued back to back as a training loop does (the host side of step i + 1 runs under
+        # the kernels of step i); forward_ms / backward_ms above are each bracketed by a synchronisation
+        n_steady = 10
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steady):
+            for prm in diff.parameters():
+                prm.grad = None
+            with torch.enable_grad():
+                diff.loss(x0).backward()
+        torch.cuda.synchronize()
+        steady = (time.perf_counter() - t0) / n_steady
         f = synth.unet_flops_per_sample(td, dim, mults, 32) * batch
         out = {"workload": f"{arch} batch {batch}: GaussianDiffusion.loss + loss.backward() (fp32)",
                "forward_ms": min(fwd) * 1e3, "backward_ms": min(bwd) * 1e3,
-               "samples_per_s": batch / (min(fwd) + min(bwd)),
+               "steady_ms_per_step": steady * 1e3,
+               "samples_per_s": batch / steady,
+               "samples_per_s_synchronised": batch / (min(fwd) + min(bwd)),
+               "conv_tflops_algorithmic_steady": 3 * f / steady / 1e12,
                "backward_conv_tflops_algorithmic": 2 * f / min(bwd) / 1e12,
                "note": "host work included (time MLPs and loss in torch, workspace allocation); weights are re-packed "
                        "on the host when parameters change — not part of this figure"}

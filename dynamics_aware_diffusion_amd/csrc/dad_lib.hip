@@ -230,6 +230,24 @@ const void* ccw_kernel(int taps, bool res, bool ride_in, int rows) {
 // Every kernel may use up to the full 160 KiB of LDS; the dynamic-LDS limit is a per-device
 // function attribute, raised once per device (not lazily per launch, so that nothing but launches
 // happens under hipGraph capture).
+// conv_wgrad instantiations by (taps, block tile): tile 0 = 64 x 64 (two K-groups), 1 = 64 x 32 (four), 2 = 32 x 32 (eight)
+template <int TAPS>
+const void* wgrad_kernel_t(int tile) {
+    return tile == 0 ? (const void*)dad::conv_wgrad<TAPS, 2, 2>
+         : tile == 1 ? (const void*)dad::conv_wgrad<TAPS, 2, 1>
+                     : (const void*)dad::conv_wgrad<TAPS, 1, 1>;
+}
+const void* wgrad_kernel(int taps, int tile) {
+    switch (taps) {
+        case 1: return wgrad_kernel_t<1>(tile);
+        case 3: return wgrad_kernel_t<3>(tile);
+        case 4: return wgrad_kernel_t<4>(tile);
+        case 5: return wgrad_kernel_t<5>(tile);
+        case 7: return wgrad_kernel_t<7>(tile);
+    }
+    return nullptr;
+}
+
 int configure_kernels() {
     static std::mutex lock;
     static std::set<int> done;
@@ -259,11 +277,9 @@ int configure_kernels() {
     HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)dad::conv_wgrad<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    for (int taps : {1, 3, 4, 5, 7})
+        for (int tile = 0; tile < 3; ++tile)
+            HIP_TRY(hipFuncSetAttribute(wgrad_kernel(taps, tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<1, 16>,
@@ -697,6 +713,7 @@ int dad_model_create(const dad_cfg* cfg, dad_model** out) {
     m->cc_enabled = getenv("DAD_NO_CC") == nullptr;
     m->chain_enabled = getenv("DAD_CHAIN") != nullptr;
     if (const char* v = getenv("DAD_CC_MAX_ROWS")) m->cc_max_rows = std::max(0, atoi(v));
+    if (const char* v = getenv("DAD_WGRAD_BLOCKS")) m->wgrad_blocks = std::max(1, atoi(v));
     if ((rc = build_plan(m.get())) != DAD_OK) return rc;
     *out = m.release();
     return DAD_OK;
@@ -1149,20 +1166,30 @@ int dad_train_grad_info(const dad_model* m, int32_t i, const char** key, int64_t
 
 namespace {
 
-struct WgradGeom { int spc, ksplit, sps; unsigned gx, gy; size_t lds; };
-WgradGeom wgrad_geom(int M, int Ctot, int B, int Lg, int Lz, int taps, int pad) {
+struct WgradGeom { int spc, ksplit, sps, tile, tm, tn; unsigned gx, gy; size_t lds; };
+// Block tile: the largest of 64 x 64 / 64 x 32 / 32 x 32 that still gives the layer 32 tiles (the smaller tiles
+// split K inside the block instead of over the grid: fewer partial slabs to write and add); the batch is then split
+// over blockIdx.z until `target` blocks exist (one block = 8 waves = two per SIMD).
+WgradGeom wgrad_geom(int M, int Ctot, int B, int Lg, int Lz, int taps, int pad, int target = 256) {
     WgradGeom g{};
     g.spc = std::max(1, dad::WG_ROWS / Lg);
-    while (g.spc > 1 && g.spc * dad::wgrad_segz(Lz, taps, pad) > 160) g.spc /= 2;     // the kernel stages <= 160 Z rows
-    g.gx = (unsigned)((M + dad::WG_TILE - 1) / dad::WG_TILE);
-    g.gy = (unsigned)((Ctot + dad::WG_TILE - 1) / dad::WG_TILE);
-    const long tiles = (long)g.gx * g.gy;
+    while (g.spc > 1 && g.spc * dad::wgrad_segz(Lz, taps, pad) > dad::WG_MAX_ZROWS) g.spc /= 2;
+    static const int tms[3] = {2, 2, 1}, tns[3] = {2, 1, 1};
+    long tiles = 0;
+    for (g.tile = 0; g.tile < 3; ++g.tile) {
+        g.tm = tms[g.tile]; g.tn = tns[g.tile];
+        g.gx = (unsigned)((M + 32 * g.tm - 1) / (32 * g.tm));
+        g.gy = (unsigned)((Ctot + 32 * g.tn - 1) / (32 * g.tn));
+        tiles = (long)g.gx * g.gy;
+        const int kgroups = 8 / (g.tm * g.tn);
+        if ((tiles >= 32 && (g.spc * Lg) % (4 * kgroups) == 0) || g.tile == 2) break;
+    }
     const int chunks = (B + g.spc - 1) / g.spc;
-    int want = (int)std::max(1L, 256 / tiles);
+    int want = (int)std::max(1L, target / tiles);
     want = std::min(want, chunks);
     g.sps = (chunks + want - 1) / want * g.spc;                // samples per split: whole chunks
     g.ksplit = (B + g.sps - 1) / g.sps;
-    g.lds = dad::wgrad_lds_floats(g.spc, Lg, Lz, taps, pad) * sizeof(float);
+    g.lds = dad::wgrad_lds_floats(g.spc, Lg, Lz, taps, pad, g.tm, g.tn) * sizeof(float);
     return g;
 }
 
@@ -1174,10 +1201,12 @@ TrainScratch train_scratch(const dad_model& m, int B) {
     const Plan& P = m.tplan;
     const int H = m.cfg.horizon, td = m.cfg.transition_dim;
     t.mirror = P.floats_per_sample * (long)B;
-    t.part = 3L * B * m.max_cout;
+    t.part = 0;                                            // every layer's per-sample partial sums, side by side
+    for (const ConvOp& f : P.convs) t.part += (f.norm.empty() ? 1L : 3L) * B * round_up(f.cout, 4);
+    t.part += (long)B * round_up(td, 4);
     long ws = 0, tmp = 0, bs = 0;
     auto wg = [&](int M, int C, int Lg, int Lz, int taps, int pad, long numel) {
-        const WgradGeom g = wgrad_geom(M, C, B, Lg, Lz, taps, pad);
+        const WgradGeom g = wgrad_geom(M, C, B, Lg, Lz, taps, pad, m.wgrad_blocks);
         if (g.ksplit > 1) ws = std::max(ws, (long)g.ksplit * numel);
     };
     for (size_t i = 0; i < P.convs.size(); ++i) {
@@ -1273,7 +1302,7 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
     const Plan& P = m->tplan;
     const std::vector<ConvOp>& convs = P.convs;
     const dad_cfg& c = m->cfg;
-    const int H = c.horizon, td = c.transition_dim, tdp = round_up(td, 32), maxC = m->max_cout;
+    const int H = c.horizon, td = c.transition_dim, tdp = round_up(td, 32);
     float* const saved = (float*)saved_v;
     float* const mirror = (float*)scratch_v;
     float* const part = mirror + ts.mirror;
@@ -1299,21 +1328,26 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
         HIP_TRY(hipGetLastError());
         return DAD_OK;
     };
-    auto col_sums = [&](float* out, const float* p, int C) -> int {
-        hipLaunchKernelGGL(dad::col_sums_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, out, p, B, C, C);
-        HIP_TRY(hipGetLastError());
-        return DAD_OK;
-    };
+    // per-sample partial sums of every layer live side by side in `part`; ONE launch at the end reduces them all
+    std::vector<std::tuple<float*, const float*, int>> sums;      // (out[C], part[B][C], C)
+    long part_used = 0;
+    auto part_take = [&](int C) -> float* { float* q = part + part_used; part_used += (long)B * round_up(C, 4); return q; };
     auto bias_grad = [&](float* out, const float* g, int rows_per_sample, int C) -> int {
-        hipLaunchKernelGGL(dad::row_partial_sums_kernel, dim3(B), dim3(256), 0, st, part, g, rows_per_sample, C, C);
+        float* q = part_take(C);
+        hipLaunchKernelGGL(dad::row_partial_sums_kernel, dim3(B), dim3(256), 0, st, q, g, rows_per_sample, C, C);
         HIP_TRY(hipGetLastError());
-        return col_sums(out, part, C);
+        sums.emplace_back(out, q, C);
+        return DAD_OK;
     };
     auto wgrad = [&](const float* Gp, int ldg, int M, const float* Z0, int C0, const float* Z1, int C1, float* out,
                      int taps, int stride, int pad, int Lg, int Lz) -> int {
-        const WgradGeom g = wgrad_geom(M, C0 + C1, B, Lg, Lz, taps, pad);
-        if (g.lds > dad::kLdsBytes || g.spc * Lg > 128 || g.spc * dad::wgrad_segz(Lz, taps, pad) > 160)
-            return fail(DAD_E_INVALID, "wgrad: a chunk of %d samples x %d rows exceeds the kernel's staging", g.spc, Lz);
+        const WgradGeom g = wgrad_geom(M, C0 + C1, B, Lg, Lz, taps, pad, m->wgrad_blocks);
+        const int kgroups = 8 / (g.tm * g.tn);
+        if (g.lds > dad::kLdsBytes || g.spc * Lg > dad::WG_MAX_GROWS || g.spc * dad::wgrad_segz(Lz, taps, pad) > dad::WG_MAX_ZROWS ||
+            (g.spc * Lg) % (4 * kgroups) != 0)
+            return fail(DAD_E_INVALID, "wgrad: a chunk of %d samples x %d rows does not fit the kernel's staging", g.spc, Lz);
+        const void* fn = wgrad_kernel(taps, g.tile);
+        if (fn == nullptr) return fail(DAD_E_INVALID, "wgrad: %d taps", taps);
         dad::WgradParams p{};
         p.G = Gp; p.ldg = ldg; p.M = M;
         p.Z0 = Z0; p.ldz0 = C0; p.C0 = C0; p.Z1 = Z1; p.ldz1 = C1; p.C1 = C1;
@@ -1322,18 +1356,12 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
         p.B = B; p.Lg = Lg; p.Lz = Lz; p.lg_shift = ilog2(Lg); p.stride = stride; p.pad = pad;
         p.ksplit = g.ksplit; p.samples_per_split = g.sps; p.spc = g.spc;
         const dim3 grid(g.gx, g.gy, (unsigned)g.ksplit);
-        switch (taps) {
-            case 1: hipLaunchKernelGGL(dad::conv_wgrad<1>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
-            case 3: hipLaunchKernelGGL(dad::conv_wgrad<3>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
-            case 4: hipLaunchKernelGGL(dad::conv_wgrad<4>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
-            case 5: hipLaunchKernelGGL(dad::conv_wgrad<5>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
-            case 7: hipLaunchKernelGGL(dad::conv_wgrad<7>, grid, dim3(dad::WG_THREADS), g.lds, st, p); break;
-            default: return fail(DAD_E_INVALID, "wgrad: %d taps", taps);
-        }
-        HIP_TRY(hipGetLastError());
+        void* args[] = {&p};
+        HIP_TRY(hipLaunchKernel(fn, grid, dim3(dad::WG_THREADS), args, g.lds, st));
         if (g.ksplit > 1) {
-            hipLaunchKernelGGL(dad::sum_slabs_kernel, dim3((unsigned)((p.out_numel + 255) / 256)), dim3(256), 0, st, out,
-                               wslab, p.out_numel, g.ksplit);
+            if (p.out_numel % 4 != 0) return fail(DAD_E_INVALID, "wgrad: %ld gradient elements (not a multiple of 4)", p.out_numel);
+            const long n4 = p.out_numel / 4;
+            hipLaunchKernelGGL(dad::sum_slabs_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, out, wslab, n4, g.ksplit);
             HIP_TRY(hipGetLastError());
         }
         return DAD_OK;
@@ -1390,20 +1418,25 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
             gp.dA = gout; gp.h = act(f.pre); gp.stats = act(f.stats);
             gp.gamma = f.d_gamma; gp.beta = f.d_beta;
             gp.dH = mirror + P.bufs[f.pre].offset * (long)B;
-            gp.part_dgamma = part; gp.part_dbeta = part + (long)B * maxC; gp.part_dbias = part + 2L * B * maxC;
+            gp.part_dgamma = part_take(f.cout); gp.part_dbeta = part_take(f.cout); gp.part_dbias = part_take(f.cout);
             gp.dtemb = f.temb_off >= 0 ? d_temb_rows + f.temb_off : nullptr;
             gp.temb_stride = P.temb_width;
             gp.C = f.cout; gp.L = f.Lout; gp.cpg = f.cout / 8;
-            hipLaunchKernelGGL(dad::gn_mish_bwd_kernel, dim3(B, 8), dim3(dad::GNB_THREADS), 0, st, gp);
-            HIP_TRY(hipGetLastError());
-            // (the partial arrays are [B][C] with C = this conv's width): the three reductions in one launch
-            {
-                dad::ColSums3 cs{};
-                cs.out[0] = G(f.norm + ".weight"); cs.out[1] = G(f.norm + ".bias"); cs.out[2] = G(f.name + ".bias");
-                cs.part[0] = gp.part_dgamma; cs.part[1] = gp.part_dbeta; cs.part[2] = gp.part_dbias;
-                hipLaunchKernelGGL(dad::col_sums3_kernel, dim3((unsigned)((f.cout + 31) / 32), 3), dim3(256), 0, st, cs, B, f.cout, f.cout);
-                HIP_TRY(hipGetLastError());
+            gp.B = B;
+            {   // one wave per (sample, group) pair while the pair fits its registers, else one block per pair
+                const int f4 = gp.cpg / 4 * gp.L;
+                const dim3 wgrid((unsigned)((B * 8 + 3) / 4));
+                if (f4 <= 64) hipLaunchKernelGGL(dad::gn_mish_bwd_wave_kernel<1>, wgrid, dim3(256), 0, st, gp);
+                else if (f4 <= 128) hipLaunchKernelGGL(dad::gn_mish_bwd_wave_kernel<2>, wgrid, dim3(256), 0, st, gp);
+                else if (f4 <= 256) hipLaunchKernelGGL(dad::gn_mish_bwd_wave_kernel<4>, wgrid, dim3(256), 0, st, gp);
+                else if (f4 <= 512) hipLaunchKernelGGL(dad::gn_mish_bwd_wave_kernel<8>, wgrid, dim3(256), 0, st, gp);
+                else if (f4 <= 1024) hipLaunchKernelGGL(dad::gn_mish_bwd_wave_kernel<16>, wgrid, dim3(256), 0, st, gp);
+                else hipLaunchKernelGGL(dad::gn_mish_bwd_kernel, dim3(B, 8), dim3(dad::GNB_THREADS), 0, st, gp);
             }
+            HIP_TRY(hipGetLastError());
+            sums.emplace_back(G(f.norm + ".weight"), gp.part_dgamma, f.cout);
+            sums.emplace_back(G(f.norm + ".bias"), gp.part_dbeta, f.cout);
+            sums.emplace_back(G(f.name + ".bias"), gp.part_dbias, f.cout);
             dH = gp.dH;
         } else {
             if ((rc = bias_grad(G(f.name + ".bias"), dH, out_rows, f.cout)) != DAD_OK) return rc;
@@ -1425,6 +1458,18 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
             const int target = k == 0 ? f.src0 : f.src1;
             if ((rc = dgrad(b.op[k], dH, target, (long)B * f.Lin * b.c_n[k])) != DAD_OK) return rc;
         }
+    }
+    if (part_used > ts.part) return fail(DAD_E_WORKSPACE, "backward: partial sums overran their region (%ld > %ld floats)", part_used, ts.part);
+    for (size_t at = 0; at < sums.size(); at += dad::COLS_MAX) {
+        dad::ColSumsMany cs{};
+        const int n = (int)std::min<size_t>(dad::COLS_MAX, sums.size() - at);
+        int widest = 0;
+        for (int k = 0; k < n; ++k) {
+            cs.out[k] = std::get<0>(sums[at + k]); cs.part[k] = std::get<1>(sums[at + k]); cs.C[k] = std::get<2>(sums[at + k]);
+            widest = std::max(widest, cs.C[k]);
+        }
+        hipLaunchKernelGGL(dad::col_sums_many_kernel, dim3((unsigned)((widest + 31) / 32), (unsigned)n), dim3(256), 0, st, cs, B);
+        HIP_TRY(hipGetLastError());
     }
     if (d_x != nullptr) {
         if (!dx_written) return fail(DAD_E_STATE, "backward: no gradient reached the trajectory");
@@ -1478,6 +1523,7 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value) {
     else if (key == "ccw_prefer16") m->ccw_prefer16 = value != 0;
     else if (key == "chain") m->chain_enabled = value != 0;
     else if (key == "chain_min_batch") m->chain_min_batch = std::max(1, (int)value);
+    else if (key == "wgrad_blocks") m->wgrad_blocks = std::max(1, (int)value);
     else return fail(DAD_E_INVALID, "unknown option '%s'", name);
     // every option changes which launches a captured loop holds, and not all of them are part of the
     // graph key: drop the cache (a replay may still be in flight: wait for the device first)

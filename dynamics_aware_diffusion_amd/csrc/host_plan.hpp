@@ -151,6 +151,7 @@ struct HostModel {
                                                                //   for the five launches it replaces
     int chain_min_batch = 64;                                  //   from this batch on (one block per sample: below, the
                                                                //   chip is mostly idle and the batch kernels' split-K wins)
+    int wgrad_blocks = 256;                                    // blocks a weight-gradient launch aims for (tiles x batch splits)
     bool ccw_prefer16 = true;                                  //   two 16-row tiles instead of an LDS-short 32-row one
                                                                //   (measured crossover: batch 16 at H = 32)
     std::map<std::vector<int>, uint64_t> xswz_cache;           // find_xswz memo

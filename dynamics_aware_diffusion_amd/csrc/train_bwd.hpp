@@ -5,10 +5,10 @@
 // Linear.  Here the data gradients of the convs run on the forward conv-GEMM kernel with transposed,
 // tap-flipped weight images (dad_lib.hip, "backward plan"); this file holds the rest:
 //
-//   conv_wgrad<TAPS>   dW[m][c][k] = sum_{b,l} dH[b,l,m] * X[b, l*stride + k - pad, c]     (MFMA GEMM, K = B*L)
+//   conv_wgrad<TAPS,TM,TN>   dW[m][c][k] = sum_{b,l} dH[b,l,m] * X[b, l*stride + k - pad, c]     (MFMA GEMM, K = B*L)
 //   gn_mish_bwd        dH = d(conv + bias) of  Mish(GroupNorm(h)) (+ time embedding), per (sample, group),
 //                      with the per-sample partial sums of d gamma, d beta, d bias and d(time projection)
-//   row_partial_sums / col_sums / sum_slabs / add_inplace      deterministic reductions (fixed order, no atomics)
+//   row_partial_sums / col_sums_many / sum_slabs / add_inplace deterministic reductions (fixed order, no atomics)
 //
 // Everything is fp32 and bit-reproducible run to run.
 #pragma once
@@ -37,13 +37,17 @@ struct WgradParams {
     int32_t ksplit, samples_per_split, spc;  // batch split over blockIdx.z; samples per staged chunk
 };
 
-constexpr int WG_TILE = 64;                  // block tile: 64 (m) x 64 (c), 4 waves of 32 x 32 x TAPS
-constexpr int WG_THREADS = 256;
+constexpr int WG_THREADS = 512;              // 8 waves: TM x TN wave tiles of 32 x 32 (x TAPS), the rest split K
 constexpr int WG_ROWS = 64;                  // G rows per staged chunk: spc = max(1, 64 / Lg) whole samples
+constexpr int WG_MAX_GROWS = 128, WG_MAX_ZROWS = 160;      // rows one chunk may stage (registers of chunk_load)
 
 __host__ __device__ inline int wgrad_segz(int Lz, int taps, int pad) { return Lz + pad + (taps - 1 - pad); }
-__host__ __device__ inline size_t wgrad_lds_floats(int spc, int Lg, int Lz, int taps, int pad) {
-    return (size_t)spc * Lg * WG_TILE + (size_t)spc * wgrad_segz(Lz, taps, pad) * WG_TILE;
+// LDS floats: the staged chunk (G rows [spc * Lg][32 TM], Z rows with halo [spc * SEGZ][32 TN]), and afterwards the
+// K-group reduction tree, whose first round parks half of the block's accumulators: 4 waves x TAPS x 16 x 64.
+__host__ __device__ inline size_t wgrad_lds_floats(int spc, int Lg, int Lz, int taps, int pad, int tm, int tn) {
+    const size_t stage = (size_t)spc * Lg * 32 * tm + (size_t)spc * wgrad_segz(Lz, taps, pad) * 32 * tn;
+    const size_t red = (size_t)4 * taps * 16 * 64;
+    return stage > red ? stage : red;
 }
 
 // four consecutive columns of a row, zero beyond `ncols`; vector load when the row is 16-byte aligned
@@ -57,20 +61,31 @@ __device__ __forceinline__ float4 wg_load4(const float* row, int col, int ncols,
     return v;
 }
 
-template <int TAPS>
+// Block = 8 waves = (TM x TN) wave tiles x KG K-groups, KG = 8 / (TM TN): a 64 x 64 block tile with two K-groups
+// for layers with many tiles, 64 x 32 with four and 32 x 32 with eight for layers with few (the batch then splits
+// over fewer blocks: less slab traffic, and the chip still holds two waves per SIMD).  All waves stage a chunk
+// together; K-group g runs the chunk's steps [g, g + 1) * steps / KG with its fragments read one step ahead; the
+// groups' accumulators meet in a fixed-shape tree through LDS (bit-reproducible), group 0 stores.
+template <int TAPS, int TM, int TN>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
+    constexpr int NT = TM * TN, KG = 8 / NT;
+    constexpr int WMW = 32 * TM, WNW = 32 * TN;              // staged columns of G / Z
+    constexpr int GQ = WMW / 4, ZQ = WNW / 4;                // float4 per staged row
+    constexpr int WG_GI = (WG_MAX_GROWS * GQ + WG_THREADS - 1) / WG_THREADS;
+    constexpr int WG_ZI = (WG_MAX_ZROWS * ZQ + WG_THREADS - 1) / WG_THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wt = wave % NT, kg = wave / NT;
+    const int wm = wt % TM, wn = wt / TM;
     const int l32 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * WG_TILE, c0 = blockIdx.y * WG_TILE;
+    const int m0 = blockIdx.x * WMW, c0 = blockIdx.y * WNW;
     const int ks = blockIdx.z;
     const int Lg = p.Lg, Lz = p.Lz;
     const int SEGZ = wgrad_segz(Lz, TAPS, p.pad);
     const int spc = p.spc;
-    float* const Gs = smem;                                  // [spc * Lg][64]
-    float* const Zs = smem + spc * Lg * WG_TILE;             // [spc * SEGZ][64]
+    float* const Gs = smem;                                  // [spc * Lg][WMW]
+    float* const Zs = smem + spc * Lg * WMW;                 // [spc * SEGZ][WNW]
     const int s_lo = ks * p.samples_per_split;
     const int s_hi = min(p.B, s_lo + p.samples_per_split);
     const int Ctot = p.C0 + p.C1;
@@ -82,11 +97,9 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // A chunk = spc whole samples: G rows [spc * Lg][64] and Z rows with their zero halo [spc * SEGZ][64].
-    // The loads of chunk i + 1 are issued before the MFMA loop of chunk i and land under it (registers:
-    // up to WG_GI + WG_ZI float4 per thread), then go to LDS behind the barrier.
-    constexpr int WG_GI = 8, WG_ZI = 10;                     // covers 128 G rows / 160 Z rows per chunk
-    const int n_g = spc * Lg * (WG_TILE / 4), n_z = spc * SEGZ * (WG_TILE / 4);
+    // A chunk = spc whole samples.  The loads of chunk i + 1 are issued before the MFMA loop of chunk i and land
+    // under it (registers: WG_GI + WG_ZI float4 per thread), then go to LDS behind the barrier.
+    const int n_g = spc * Lg * GQ, n_z = spc * SEGZ * ZQ;
     float4 gr[WG_GI], zr[WG_ZI];
     auto chunk_load = [&](int sb) {
 #pragma unroll
@@ -94,7 +107,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
             const int i = tid + k * WG_THREADS;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n_g) {
-                const int row = i >> 4, q = i & 15;
+                const int row = i / GQ, q = i % GQ;
                 const int smp = sb + (row >> p.lg_shift), l = row & (Lg - 1);
                 if (smp < s_hi) v = wg_load4(p.G + (long)(smp * Lg + l) * p.ldg, m0 + 4 * q, p.M, gvec);
             }
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
             const int i = tid + k * WG_THREADS;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n_z) {
-                const int row = i >> 4, q = i & 15;
+                const int row = i / ZQ, q = i % ZQ;
                 const int sl = row / SEGZ, pz = row - sl * SEGZ - p.pad;
                 const int smp = sb + sl;
                 const int c = c0 + 4 * q;
@@ -117,32 +130,74 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
             zr[k] = v;
         }
     };
+    // fragments of step s (rows 2s, 2s + 1; lane half h takes row 2s + h): one G value, TAPS Z values
+    auto frag = [&](int s, float& a, float (&z)[TAPS]) {
+        const int row = 2 * s + h;
+        const int sl = row >> p.lg_shift, l = row & (Lg - 1);
+        a = Gs[row * WMW + wm * 32 + l32];
+        const float* zb = Zs + (sl * SEGZ + l * p.stride) * WNW + wn * 32 + l32;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) z[t] = zb[t * WNW];
+    };
+    const int spg = (spc * Lg) / (2 * KG);                   // steps of a chunk per K-group (host: divides, even)
+    const int s_first = kg * spg, s_last = s_first + spg - 1;
     chunk_load(s_lo);
     for (int sb = s_lo; sb < s_hi; sb += spc) {
         __syncthreads();                                     // the previous chunk's fragment reads are done
 #pragma unroll
         for (int k = 0; k < WG_GI; ++k) {
             const int i = tid + k * WG_THREADS;
-            if (i < n_g) *reinterpret_cast<float4*>(Gs + (i >> 4) * WG_TILE + 4 * (i & 15)) = gr[k];
+            if (i < n_g) *reinterpret_cast<float4*>(Gs + 4 * i) = gr[k];
         }
 #pragma unroll
         for (int k = 0; k < WG_ZI; ++k) {
             const int i = tid + k * WG_THREADS;
-            if (i < n_z) *reinterpret_cast<float4*>(Zs + (i >> 4) * WG_TILE + 4 * (i & 15)) = zr[k];
+            if (i < n_z) *reinterpret_cast<float4*>(Zs + 4 * i) = zr[k];
         }
         __syncthreads();
         if (sb + spc < s_hi) chunk_load(sb + spc);           // in flight under the MFMAs below
-        // ---- K loop over the chunk's rows: k = row (lane half h takes row kk + h)
-        const int nrows = spc * Lg;
-        for (int kk = 0; kk < nrows; kk += 2) {
-            const int row = kk + h;
-            const int sl = row >> p.lg_shift, l = row & (Lg - 1);
-            const float a = Gs[row * WG_TILE + wm * 32 + l32];
-            const float* zb = Zs + (sl * SEGZ + l * p.stride) * WG_TILE + wn * 32 + l32;
+        // Two steps per round on two register sets, each set's LDS reads issued a whole step ahead of its MFMAs
+        // (hipcc otherwise sinks the reads to their use: one LDS round trip exposed per step).
+        float a0, z0[TAPS], a1, z1[TAPS];
+        frag(s_first, a0, z0);
+        for (int s = s_first; s < s_last; s += 2) {          // (host: an even number of steps per K-group)
+            frag(s + 1, a1, z1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < TAPS; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zb[t * WG_TILE], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, z0[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(min(s + 2, s_last), a0, z0);                // (the last round re-reads a step it does not use)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, z1[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    // ---- the K-groups meet: groups [half, 2 half) park their accumulators, groups [0, half) add them
+    if constexpr (KG > 1) {
+        __syncthreads();                                     // staging LDS is free
+#pragma unroll
+        for (int half = KG / 2; half >= 1; half >>= 1) {
+            if (kg >= half && kg < 2 * half) {
+                float* dst = smem + ((kg - half) * NT + wt) * (TAPS * 16 * 64) + lane;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = acc[t][r];
+            }
+            __syncthreads();
+            if (kg < half) {
+                const float* src = smem + (kg * NT + wt) * (TAPS * 16 * 64) + lane;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += src[(t * 16 + r) * 64];
+            }
+            if (half > 1) __syncthreads();
+        }
+        if (kg != 0) return;
     }
     // ---- store: D row = m (first operand), column = c
     float* const out = p.out + (p.ksplit > 1 ? (long)ks * p.out_numel : 0L);
@@ -215,13 +270,33 @@ __global__ void repack_kernel(const RepackParams p) {
     p.dst[d] = v;
 }
 
-// out[i] = sum_k slab[k][i], k in order
-__global__ void sum_slabs_kernel(float* out, const float* slab, long n, int ks) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float v = slab[i];
-    for (int k = 1; k < ks; ++k) v += slab[(long)k * n + i];
-    out[i] = v;
+// out[i] = sum_k slab[k][i].  Thread (i, g) of a block adds slabs g, g + 4, g + 8, ... of float4 i (four loads in
+// flight per thread, four times the threads of a one-thread-per-element loop: a level-0 conv of PointMaze has 64
+// slabs of 82 k floats), the four partial sums meet in LDS and are added in group order — fixed order, no atomics.
+// n4 = n / 4 (n is a multiple of 4: one of M, C is a multiple of 32).  grid = ceil(n4 / 64), 256 threads.
+__global__ __launch_bounds__(256) void sum_slabs_kernel(float* out, const float* slab, long n4, int ks) {
+    __shared__ float4 red[3][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (i < n4) {
+        const float4* s4 = reinterpret_cast<const float4*>(slab) + i;
+        int k = g;
+        for (; k + 4 < ks; k += 8) {
+            const float4 u = s4[(long)k * n4], v = s4[(long)(k + 4) * n4];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        if (k < ks) { const float4 u = s4[(long)k * n4]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (g > 0) red[g - 1][col] = a;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const float4 v = red[q][col]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        reinterpret_cast<float4*>(out)[i] = a;
+    }
 }
 
 // y[i] += x[i]   (n4 float4s)
@@ -272,24 +347,30 @@ __global__ __launch_bounds__(256) void col_sums_kernel(float* out, const float* 
     }
 }
 
-// the same for three [B][C] arrays at once (blockIdx.y picks one): d gamma, d beta, d bias of one conv
-struct ColSums3 { float* out[3]; const float* part[3]; };
-__global__ __launch_bounds__(256) void col_sums3_kernel(const ColSums3 a, int B, int stride, int C) {
+// The same for MANY [B][C] arrays in one launch (blockIdx.y picks the array): every layer of a backward pass parks
+// its per-sample partial sums (d gamma, d beta, d bias) in a region of its own and ONE launch at the end of the pass
+// reduces them all — 45 launches of ~5 us each on a PointMaze step become one.  The descriptors travel as kernel
+// arguments (no upload): at most COLS_MAX per launch.
+constexpr int COLS_MAX = 120;
+struct ColSumsMany { float* out[COLS_MAX]; const float* part[COLS_MAX]; int32_t C[COLS_MAX]; };
+__global__ __launch_bounds__(256) void col_sums_many_kernel(const ColSumsMany a, int B) {
     __shared__ float red[8][33];
-    const float* part = blockIdx.y == 0 ? a.part[0] : (blockIdx.y == 1 ? a.part[1] : a.part[2]);
-    float* out = blockIdx.y == 0 ? a.out[0] : (blockIdx.y == 1 ? a.out[1] : a.out[2]);
+    const int C = a.C[blockIdx.y];
+    if ((int)blockIdx.x * 32 >= C) return;               // (whole blocks leave)
+    const float* part = a.part[blockIdx.y];
+    float* out = a.out[blockIdx.y];
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + col;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < C) {
         int b = rg;
         for (; b + 24 < B; b += 32) {
-            a0 += part[(long)b * stride + c];
-            a1 += part[(long)(b + 8) * stride + c];
-            a2 += part[(long)(b + 16) * stride + c];
-            a3 += part[(long)(b + 24) * stride + c];
+            a0 += part[(long)b * C + c];
+            a1 += part[(long)(b + 8) * C + c];
+            a2 += part[(long)(b + 16) * C + c];
+            a3 += part[(long)(b + 24) * C + c];
         }
-        for (; b < B; b += 8) a0 += part[(long)b * stride + c];
+        for (; b < B; b += 8) a0 += part[(long)b * C + c];
     }
     red[rg][col] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -318,6 +399,7 @@ struct GnBwdParams {
     float* dtemb;         // [B][temb_stride] + temb_off, or nullptr
     int32_t temb_stride;
     int32_t C, L, cpg;
+    int32_t B;
 };
 
 __device__ __forceinline__ float mish_grad_f32(float u) {
@@ -410,6 +492,98 @@ __global__ __launch_bounds__(GNB_THREADS) void gn_mish_bwd_kernel(const GnBwdPar
         if (p.dtemb != nullptr) {
             float* t = p.dtemb + (long)b * p.temb_stride + cbase;
             t[0] = acc[12]; t[1] = acc[13]; t[2] = acc[14]; t[3] = acc[15];
+        }
+    }
+}
+
+// The same with ONE WAVE per (sample, group) pair, for pairs of up to 16 x 64 float4 (every layer of the three
+// BASELINE nets at horizon 32): both tensors are read once and stay in registers between the two passes, the pair
+// sums are wave reductions (xor butterflies: a fixed tree, bit-reproducible) — no LDS, no block barrier.  Lane
+// mapping: float4 e = v * 64 + lane covers channel quad q = e % nq at position l = e / nq (nq = cpg / 4, a power of
+// two <= 64, so a lane keeps its quad for every v); per-channel sums meet across the lanes that share q.
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+template <int NV>
+__global__ __launch_bounds__(256) void gn_mish_bwd_wave_kernel(const GnBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= p.B * 8) return;                   // (whole waves leave: no barrier below)
+    const int b = pair >> 3, g = pair & 7;
+    const int C = p.C, L = p.L, cpg = p.cpg;
+    const int nq = cpg >> 2, count = nq * L;
+    const int nq_shift = 31 - __builtin_clz(nq);
+    const int q = lane & (nq - 1);
+    const int cbase = g * cpg + 4 * q;
+    const float mean = p.stats[((long)b * 8 + g) * 2], rstd = p.stats[((long)b * 8 + g) * 2 + 1];
+    const float4 gam = ldg4(p.gamma + cbase), bet = ldg4(p.beta + cbase);
+    const float gm[4] = {gam.x, gam.y, gam.z, gam.w}, bt[4] = {bet.x, bet.y, bet.z, bet.w};
+    const float inv_n = 1.0f / (float)(cpg * L);
+
+    float4 hv[NV], da[NV];
+    long off[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {                 // unconditional loads (clamped index), masked at the use
+        const int e = min(v * 64 + lane, count - 1);
+        off[v] = ((long)b * L + (e >> nq_shift)) * C + cbase;
+        hv[v] = ldg4(p.h + off[v]);
+        da[v] = ldg4(p.dA + off[v]);
+    }
+    // pass 1: du = dA mish'(u) and xh replace dA and h in the registers; the two pair sums; sum_l dA
+    float s1 = 0.0f, s2 = 0.0f;
+    float pt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool live = v * 64 + lane < count;
+        float x[4] = {hv[v].x, hv[v].y, hv[v].z, hv[v].w}, d[4] = {da[v].x, da[v].y, da[v].z, da[v].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (x[j] - mean) * rstd;
+            const float du = live ? d[j] * mish_grad_f32(gm[j] * xh + bt[j]) : 0.0f;
+            pt[j] += live ? d[j] : 0.0f;
+            const float dxh = du * gm[j];
+            s1 += dxh;
+            s2 += dxh * xh;
+            x[j] = xh; d[j] = du;
+        }
+        hv[v] = make_float4(x[0], x[1], x[2], x[3]);
+        da[v] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    const float m1 = wave_sum_all(s1) * inv_n, m2 = wave_sum_all(s2) * inv_n;
+    // pass 2: dH and this sample's per-channel sums
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, pbias[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool live = v * 64 + lane < count;
+        const float x[4] = {hv[v].x, hv[v].y, hv[v].z, hv[v].w}, d[4] = {da[v].x, da[v].y, da[v].z, da[v].w};
+        float dh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dh[j] = live ? rstd * (d[j] * gm[j] - m1 - x[j] * m2) : 0.0f;
+            pg[j] += d[j] * x[j];
+            pb[j] += d[j];
+            pbias[j] += dh[j];
+        }
+        if (live) *reinterpret_cast<float4*>(p.dH + off[v]) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+    }
+    for (int s = nq; s < 64; s <<= 1)              // lanes q, q + nq, q + 2 nq, ... hold the same channels
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pg[j] += __shfl_xor(pg[j], s, 64);
+            pb[j] += __shfl_xor(pb[j], s, 64);
+            pbias[j] += __shfl_xor(pbias[j], s, 64);
+            pt[j] += __shfl_xor(pt[j], s, 64);
+        }
+    if (lane < nq) {
+        const long po = (long)b * C + cbase;
+        *reinterpret_cast<float4*>(p.part_dgamma + po) = make_float4(pg[0], pg[1], pg[2], pg[3]);
+        *reinterpret_cast<float4*>(p.part_dbeta + po) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+        *reinterpret_cast<float4*>(p.part_dbias + po) = make_float4(pbias[0], pbias[1], pbias[2], pbias[3]);
+        if (p.dtemb != nullptr) {
+            float* t = p.dtemb + (long)b * p.temb_stride + cbase;
+            t[0] = pt[0]; t[1] = pt[1]; t[2] = pt[2]; t[3] = pt[3];
         }
     }
 }

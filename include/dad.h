@@ -273,7 +273,8 @@ int dad_profile_read(dad_model* m, double* conv_ms, int64_t* conv_launches, doub
  * "ccw_min_blocks" (blocks a wide layer keeps when its K slices are fattened), "ccw_prefer16" (two
  * 16-row tiles instead of a 32-row tile whose K slice LDS would halve), "chain" (nets of dim <= 128 at
  * horizon 32: the five level-0 encoder launches as one launch per sample, csrc/conv_chain.hpp; off by
- * default — measured slower than the launches it replaces), "chain_min_batch".
+ * default — measured slower than the launches it replaces), "chain_min_batch", "wgrad_blocks" (blocks a
+ * weight-gradient launch of the backward pass aims for: tiles x batch splits).
  * Results do not depend on these choices beyond fp32 summation order. */
 int dad_debug_set_tile(dad_model* m, int32_t cfg);
 int dad_debug_set_option(dad_model* m, const char* name, int32_t value);

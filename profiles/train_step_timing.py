@@ -46,6 +46,18 @@ for rep in range(args.repeats + 1):
     if rep:
         fwd.append(t1 - t0)
         bwd.append(t2 - t1)
+# steady state: steps back to back as a training loop issues them (no synchronisation in between — the host side of
+# step i + 1 runs under the kernels of step i)
+N = 10
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    for p in diff.parameters():
+        p.grad = None
+    diff.loss(x0).backward()
+torch.cuda.synchronize()
+steady = (time.perf_counter() - t0) / N
 fm, bm = min(fwd) * 1e3, min(bwd) * 1e3
 print(f"{args.arch} B={args.batch}: training forward {fm:.2f} ms ({f / fm / 1e9:.1f} TFLOP/s), backward {bm:.2f} ms "
-      f"({2 * f / bm / 1e9:.1f} TFLOP/s algorithmic), loss {float(loss):.5f}", flush=True)
+      f"({2 * f / bm / 1e9:.1f} TFLOP/s algorithmic), {N} steps back to back {steady * 1e3:.2f} ms per step "
+      f"({3 * f / steady / 1e12:.1f} TFLOP/s, {args.batch / steady:.0f} samples/s), loss {float(loss):.5f}", flush=True)
