@@ -230,12 +230,15 @@ const void* ccw_kernel(int taps, bool res, bool ride_in, int rows) {
 // Every kernel may use up to the full 160 KiB of LDS; the dynamic-LDS limit is a per-device
 // function attribute, raised once per device (not lazily per launch, so that nothing but launches
 // happens under hipGraph capture).
-// conv_wgrad instantiations by (taps, block tile): tile 0 = 64 x 64 (two K-groups), 1 = 64 x 32 (four), 2 = 32 x 32 (eight)
+// conv_wgrad instantiations by (taps, block tile): tile 0 = 64 x 64 (two K-groups), 1 = 64 x 32 (four), 2 = 32 x 32
+// (eight); tile 3 = 32 x 32 with the general staging path (operands that are not whole aligned float4 rows)
+constexpr int kWgradTiles = 4;
 template <int TAPS>
 const void* wgrad_kernel_t(int tile) {
-    return tile == 0 ? (const void*)dad::conv_wgrad<TAPS, 2, 2>
-         : tile == 1 ? (const void*)dad::conv_wgrad<TAPS, 2, 1>
-                     : (const void*)dad::conv_wgrad<TAPS, 1, 1>;
+    return tile == 0 ? (const void*)dad::conv_wgrad<TAPS, 2, 2, true>
+         : tile == 1 ? (const void*)dad::conv_wgrad<TAPS, 2, 1, true>
+         : tile == 2 ? (const void*)dad::conv_wgrad<TAPS, 1, 1, true>
+                     : (const void*)dad::conv_wgrad<TAPS, 1, 1, false>;
 }
 const void* wgrad_kernel(int taps, int tile) {
     switch (taps) {
@@ -278,7 +281,7 @@ int configure_kernels() {
     HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::chain_l0_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     for (int taps : {1, 3, 4, 5, 7})
-        for (int tile = 0; tile < 3; ++tile)
+        for (int tile = 0; tile < kWgradTiles; ++tile)
             HIP_TRY(hipFuncSetAttribute(wgrad_kernel(taps, tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     HIP_TRY(hipFuncSetAttribute((const void*)dad::project_kernel<4, 16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
@@ -1170,13 +1173,13 @@ struct WgradGeom { int spc, ksplit, sps, tile, tm, tn; unsigned gx, gy; size_t l
 // Block tile: the largest of 64 x 64 / 64 x 32 / 32 x 32 that still gives the layer 32 tiles (the smaller tiles
 // split K inside the block instead of over the grid: fewer partial slabs to write and add); the batch is then split
 // over blockIdx.z until `target` blocks exist (one block = 8 waves = two per SIMD).
-WgradGeom wgrad_geom(int M, int Ctot, int B, int Lg, int Lz, int taps, int pad, int target = 256) {
+WgradGeom wgrad_geom(int M, int Ctot, int B, int Lg, int Lz, int taps, int pad, int target = 256, bool ragged = false) {
     WgradGeom g{};
     g.spc = std::max(1, dad::WG_ROWS / Lg);
     while (g.spc > 1 && g.spc * dad::wgrad_segz(Lz, taps, pad) > dad::WG_MAX_ZROWS) g.spc /= 2;
     static const int tms[3] = {2, 2, 1}, tns[3] = {2, 1, 1};
     long tiles = 0;
-    for (g.tile = 0; g.tile < 3; ++g.tile) {
+    for (g.tile = ragged ? 2 : 0; g.tile < 3; ++g.tile) {
         g.tm = tms[g.tile]; g.tn = tns[g.tile];
         g.gx = (unsigned)((M + 32 * g.tm - 1) / (32 * g.tm));
         g.gy = (unsigned)((Ctot + 32 * g.tn - 1) / (32 * g.tn));
@@ -1190,6 +1193,7 @@ WgradGeom wgrad_geom(int M, int Ctot, int B, int Lg, int Lz, int taps, int pad, 
     g.sps = (chunks + want - 1) / want * g.spc;                // samples per split: whole chunks
     g.ksplit = (B + g.sps - 1) / g.sps;
     g.lds = dad::wgrad_lds_floats(g.spc, Lg, Lz, taps, pad, g.tm, g.tn) * sizeof(float);
+    if (ragged) g.tile = 3;
     return g;
 }
 
@@ -1205,18 +1209,18 @@ TrainScratch train_scratch(const dad_model& m, int B) {
     for (const ConvOp& f : P.convs) t.part += (f.norm.empty() ? 1L : 3L) * B * round_up(f.cout, 4);
     t.part += (long)B * round_up(td, 4);
     long ws = 0, tmp = 0, bs = 0;
-    auto wg = [&](int M, int C, int Lg, int Lz, int taps, int pad, long numel) {
-        const WgradGeom g = wgrad_geom(M, C, B, Lg, Lz, taps, pad, m.wgrad_blocks);
+    auto wg = [&](int M, int C0, int C1, int Lg, int Lz, int taps, int pad, long numel) {
+        const WgradGeom g = wgrad_geom(M, C0 + C1, B, Lg, Lz, taps, pad, m.wgrad_blocks, ((M | C0 | C1) & 3) != 0);
         if (g.ksplit > 1) ws = std::max(ws, (long)g.ksplit * numel);
     };
     for (size_t i = 0; i < P.convs.size(); ++i) {
         const ConvOp& f = P.convs[i];
         const int cin = f.cin0 + f.cin1;
         switch (f.kind) {
-            case CONV_K5: case CONV_1X1: wg(f.cout, cin, f.Lin, f.Lin, f.taps, f.taps / 2, (long)f.cout * cin * f.taps); break;
-            case CONV_DOWN: wg(f.cout, cin, f.Lout, f.Lin, 3, 1, (long)f.cout * cin * 3);
+            case CONV_K5: case CONV_1X1: wg(f.cout, f.cin0, f.cin1, f.Lin, f.Lin, f.taps, f.taps / 2, (long)f.cout * cin * f.taps); break;
+            case CONV_DOWN: wg(f.cout, cin, 0, f.Lout, f.Lin, 3, 1, (long)f.cout * cin * 3);
                 tmp = std::max(tmp, (long)B * f.Lin * cin); break;
-            case CONV_UP: wg(cin, f.cout, f.Lin, 2 * f.Lin, 4, 1, (long)cin * f.cout * 4); break;
+            case CONV_UP: wg(cin, f.cout, 0, f.Lin, 2 * f.Lin, 4, 1, (long)cin * f.cout * 4); break;
         }
         for (int k = 0; k < m.bconvs[i].n; ++k) {
             const ConvOp& b = m.bconvs[i].op[k];
@@ -1224,7 +1228,7 @@ TrainScratch train_scratch(const dad_model& m, int B) {
             if (cfg >= 0) bs = std::max(bs, plan_split(m, b, cfg, B).slab_floats);
         }
     }
-    wg(td, m.cfg.dim, H, H, 1, 0, (long)td * m.cfg.dim);
+    wg(td, m.cfg.dim, 0, H, H, 1, 0, (long)td * m.cfg.dim);
     {
         const int cfg = choose_tile(m, m.bfinal, B);
         if (cfg >= 0) bs = std::max(bs, plan_split(m, m.bfinal, cfg, B).slab_floats);
@@ -1341,7 +1345,8 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
     };
     auto wgrad = [&](const float* Gp, int ldg, int M, const float* Z0, int C0, const float* Z1, int C1, float* out,
                      int taps, int stride, int pad, int Lg, int Lz) -> int {
-        const WgradGeom g = wgrad_geom(M, C0 + C1, B, Lg, Lz, taps, pad, m->wgrad_blocks);
+        const bool ragged = ((ldg | C0 | C1 | M) & 3) != 0;      // rows that are not whole aligned float4s (ld == width everywhere)
+        const WgradGeom g = wgrad_geom(M, C0 + C1, B, Lg, Lz, taps, pad, m->wgrad_blocks, ragged);
         const int kgroups = 8 / (g.tm * g.tn);
         if (g.lds > dad::kLdsBytes || g.spc * Lg > dad::WG_MAX_GROWS || g.spc * dad::wgrad_segz(Lz, taps, pad) > dad::WG_MAX_ZROWS ||
             (g.spc * Lg) % (4 * kgroups) != 0)
@@ -1355,6 +1360,7 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
         p.out = g.ksplit > 1 ? wslab : out;
         p.B = B; p.Lg = Lg; p.Lz = Lz; p.lg_shift = ilog2(Lg); p.stride = stride; p.pad = pad;
         p.ksplit = g.ksplit; p.samples_per_split = g.sps; p.spc = g.spc;
+        p.zero = m->d_zero;
         const dim3 grid(g.gx, g.gy, (unsigned)g.ksplit);
         void* args[] = {&p};
         HIP_TRY(hipLaunchKernel(fn, grid, dim3(dad::WG_THREADS), args, g.lds, st));
@@ -1492,6 +1498,13 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, u
 
 #ifdef DAD_STAMPS
 int dad_debug_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return DAD_OK; }
+#endif
+#ifdef DAD_WG_STAMPS
+extern "C" int dad_debug_wgrad_stamps(unsigned long long* host32) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(host32, HIP_SYMBOL(dad::g_wg_stamps), 32 * sizeof(unsigned long long)));
+    return DAD_OK;
+}
 #endif
 #ifdef DAD_CHAIN_STAMPS
 int dad_debug_chain_stamps(unsigned long long* host32) {

@@ -35,6 +35,7 @@ struct WgradParams {
     int32_t B, Lg, Lz, lg_shift;             // Lg = 1 << lg_shift
     int32_t stride, pad;
     int32_t ksplit, samples_per_split, spc;  // batch split over blockIdx.z; samples per staged chunk
+    const float* zero;                       // >= 16 bytes of zeros (what the LDS-DMA fetches for halo rows)
 };
 
 constexpr int WG_THREADS = 512;              // 8 waves: TM x TN wave tiles of 32 x 32 (x TAPS), the rest split K
@@ -42,10 +43,12 @@ constexpr int WG_ROWS = 64;                  // G rows per staged chunk: spc = m
 constexpr int WG_MAX_GROWS = 128, WG_MAX_ZROWS = 160;      // rows one chunk may stage (registers of chunk_load)
 
 __host__ __device__ inline int wgrad_segz(int Lz, int taps, int pad) { return Lz + pad + (taps - 1 - pad); }
-// LDS floats: the staged chunk (G rows [spc * Lg][32 TM], Z rows with halo [spc * SEGZ][32 TN]), and afterwards the
-// K-group reduction tree, whose first round parks half of the block's accumulators: 4 waves x TAPS x 16 x 64.
+__host__ __device__ inline int wgrad_round64(int v) { return (v + 63) / 64 * 64; }
+// LDS floats: two stages of a chunk (G rows [spc * Lg][32 TM], Z rows with halo [spc * SEGZ][32 TN], each part
+// rounded up to whole 64-float4 wave-instructions of the LDS-DMA), and afterwards the K-group reduction tree, whose
+// first round parks half of the block's accumulators: 4 waves x TAPS x 16 x 64.
 __host__ __device__ inline size_t wgrad_lds_floats(int spc, int Lg, int Lz, int taps, int pad, int tm, int tn) {
-    const size_t stage = (size_t)spc * Lg * 32 * tm + (size_t)spc * wgrad_segz(Lz, taps, pad) * 32 * tn;
+    const size_t stage = 2 * ((size_t)wgrad_round64(spc * Lg * 8 * tm) * 4 + (size_t)wgrad_round64(spc * wgrad_segz(Lz, taps, pad) * 8 * tn) * 4);
     const size_t red = (size_t)4 * taps * 16 * 64;
     return stage > red ? stage : red;
 }
@@ -61,12 +64,29 @@ __device__ __forceinline__ float4 wg_load4(const float* row, int col, int ncols,
     return v;
 }
 
+#ifdef DAD_WG_STAMPS
+__device__ unsigned long long g_wg_stamps[32];
+#define WG_STAMP(k) do { if (stamp_on && threadIdx.x == 0) g_wg_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
+
 // Block = 8 waves = (TM x TN) wave tiles x KG K-groups, KG = 8 / (TM TN): a 64 x 64 block tile with two K-groups
 // for layers with many tiles, 64 x 32 with four and 32 x 32 with eight for layers with few (the batch then splits
 // over fewer blocks: less slab traffic, and the chip still holds two waves per SIMD).  All waves stage a chunk
 // together; K-group g runs the chunk's steps [g, g + 1) * steps / KG with its fragments read one step ahead; the
 // groups' accumulators meet in a fixed-shape tree through LDS (bit-reproducible), group 0 stores.
-template <int TAPS, int TM, int TN>
+//
+// Staging.  Chunk i + 1 is on its way into the other LDS stage while chunk i is computed; one barrier per chunk.
+// ALIGNED (every operand row is whole 16-byte-aligned float4s: all layers but those that touch the trajectory's td
+// columns): LDS-DMA, `global_load_lds_dwordx4` — a wave-instruction moves 64 float4 to 1 KiB of LDS, no registers,
+// nothing to wait for until the chunk's closing barrier.  Every chunk has the same shape, so what a thread fetches
+// is decided ONCE: per float4 an element offset from the chunk's first row (-1: halo / beyond the tile -> a zero
+// word in global memory) and its sample.  (Register staging held the loads of the next chunk in flight across the
+// loop's back edge: hipcc put copies of the destination registers behind the loads, each with its `s_waitcnt` — a
+// memory round trip per chunk, 12 us per chunk against 5 us of MFMAs by the in-kernel stamps.)
+// !ALIGNED: registers, loaded before the chunk's MFMAs and written to the other stage behind them.
+template <int TAPS, int TM, int TN, bool ALIGNED>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
     constexpr int NT = TM * TN, KG = 8 / NT;
     constexpr int WMW = 32 * TM, WNW = 32 * TN;              // staged columns of G / Z
@@ -84,12 +104,19 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
     const int Lg = p.Lg, Lz = p.Lz;
     const int SEGZ = wgrad_segz(Lz, TAPS, p.pad);
     const int spc = p.spc;
-    float* const Gs = smem;                                  // [spc * Lg][WMW]
-    float* const Zs = smem + spc * Lg * WMW;                 // [spc * SEGZ][WNW]
+    // a stage = [G rows: spc * Lg][WMW] | [Z rows with halo: spc * SEGZ][WNW], each part rounded up to whole
+    // wave-instructions of the LDS-DMA (64 float4)
+    const int n_g = spc * Lg * GQ, n_z = spc * SEGZ * ZQ;    // float4s
+    const int zs_at = wgrad_round64(n_g) * 4;
+    const int stage_floats = zs_at + wgrad_round64(n_z) * 4;
     const int s_lo = ks * p.samples_per_split;
     const int s_hi = min(p.B, s_lo + p.samples_per_split);
     const int Ctot = p.C0 + p.C1;
-    const bool gvec = (p.ldg & 3) == 0, z0vec = (p.ldz0 & 3) == 0, z1vec = (p.ldz1 & 3) == 0;
+#ifdef DAD_WG_STAMPS
+    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && p.M == 512 && Ctot == 512;
+    int chunk_no = 0;
+#endif
+    WG_STAMP(0);
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -97,89 +124,147 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // A chunk = spc whole samples.  The loads of chunk i + 1 are issued before the MFMA loop of chunk i and land
-    // under it (registers: WG_GI + WG_ZI float4 per thread), then go to LDS behind the barrier.
-    const int n_g = spc * Lg * GQ, n_z = spc * SEGZ * ZQ;
-    float4 gr[WG_GI], zr[WG_ZI];
-    auto chunk_load = [&](int sb) {
+    // (no lambdas or macros over these arrays: a capture by reference puts them on a scratch segment)
+    int g_off[WG_GI], z_off[WG_ZI];              // ALIGNED: element offsets from the chunk's first row, -1 = zero
+    int g_smp[WG_GI], z_smp[WG_ZI];              // ALIGNED: sample of the chunk; Z: + 4096 when the source is Z1
+    float4 gr[WG_GI], zr[WG_ZI];                 // !ALIGNED: the next chunk on its way
+    if constexpr (ALIGNED) {
 #pragma unroll
         for (int k = 0; k < WG_GI; ++k) {
             const int i = tid + k * WG_THREADS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n_g) {
-                const int row = i / GQ, q = i % GQ;
-                const int smp = sb + (row >> p.lg_shift), l = row & (Lg - 1);
-                if (smp < s_hi) v = wg_load4(p.G + (long)(smp * Lg + l) * p.ldg, m0 + 4 * q, p.M, gvec);
-            }
-            gr[k] = v;
+            const int row = i / GQ, q = i % GQ, col = m0 + 4 * q;
+            g_smp[k] = row >> p.lg_shift;
+            g_off[k] = (i < n_g && col < p.M) ? (row * p.ldg + col) : -1;       // (row = sample * Lg + l)
         }
 #pragma unroll
         for (int k = 0; k < WG_ZI; ++k) {
             const int i = tid + k * WG_THREADS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n_z) {
-                const int row = i / ZQ, q = i % ZQ;
-                const int sl = row / SEGZ, pz = row - sl * SEGZ - p.pad;
-                const int smp = sb + sl;
-                const int c = c0 + 4 * q;
-                if (smp < s_hi && pz >= 0 && pz < Lz && c < Ctot) {
-                    if (c < p.C0) v = wg_load4(p.Z0 + (long)(smp * Lz + pz) * p.ldz0, c, p.C0, z0vec);
-                    else v = wg_load4(p.Z1 + (long)(smp * Lz + pz) * p.ldz1, c - p.C0, p.C1, z1vec);
-                }
-            }
-            zr[k] = v;
+            const int row = i / ZQ, q = i % ZQ, c = c0 + 4 * q;
+            const int sl = row / SEGZ, pz = row - sl * SEGZ - p.pad;
+            const bool ok = i < n_z && pz >= 0 && pz < Lz && c < Ctot;
+            const bool second = c >= p.C0;
+            z_smp[k] = sl + (second ? 4096 : 0);
+            z_off[k] = !ok ? -1 : second ? (sl * Lz + pz) * p.ldz1 + (c - p.C0) : (sl * Lz + pz) * p.ldz0 + c;
         }
-    };
+    }
+    const bool gvec = (p.ldg & 3) == 0, z0vec = (p.ldz0 & 3) == 0, z1vec = (p.ldz1 & 3) == 0;
+
     // fragments of step s (rows 2s, 2s + 1; lane half h takes row 2s + h): one G value, TAPS Z values
-    auto frag = [&](int s, float& a, float (&z)[TAPS]) {
+    auto frag = [&](const float* stage, int s, float& a, float (&z)[TAPS]) {
         const int row = 2 * s + h;
         const int sl = row >> p.lg_shift, l = row & (Lg - 1);
-        a = Gs[row * WMW + wm * 32 + l32];
-        const float* zb = Zs + (sl * SEGZ + l * p.stride) * WNW + wn * 32 + l32;
+        a = stage[row * WMW + wm * 32 + l32];
+        const float* zb = stage + zs_at + (sl * SEGZ + l * p.stride) * WNW + wn * 32 + l32;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) z[t] = zb[t * WNW];
     };
     const int spg = (spc * Lg) / (2 * KG);                   // steps of a chunk per K-group (host: divides, even)
     const int s_first = kg * spg, s_last = s_first + spg - 1;
-    chunk_load(s_lo);
-    for (int sb = s_lo; sb < s_hi; sb += spc) {
-        __syncthreads();                                     // the previous chunk's fragment reads are done
+
+    // iteration -1 only fetches chunk 0; iteration i fetches chunk i + 1 and computes chunk i
+    int cur = 1;
+    for (int sb = s_lo - spc; sb < s_hi; sb += spc, cur ^= 1) {
+        const int nb = sb + spc;                             // first sample of the chunk to fetch
+        float* const next = smem + (cur ^ 1) * stage_floats;
+        if (nb < s_hi) {
+            if constexpr (ALIGNED) {
+                const float* const gb = p.G + (long)nb * Lg * p.ldg;
+                const float* const zb0 = p.Z0 + (long)nb * Lz * p.ldz0;
+                const float* const zb1 = p.Z1 != nullptr ? p.Z1 + (long)nb * Lz * p.ldz1 : zb0;
 #pragma unroll
-        for (int k = 0; k < WG_GI; ++k) {
-            const int i = tid + k * WG_THREADS;
-            if (i < n_g) *reinterpret_cast<float4*>(Gs + 4 * i) = gr[k];
+                for (int k = 0; k < WG_GI; ++k) {
+                    const int at = wave * 64 + k * WG_THREADS;                  // the wave's first float4: uniform
+                    if (at < n_g) {
+                        const bool ok = g_off[k] >= 0 && nb + g_smp[k] < s_hi;
+                        const float* src = ok ? gb + g_off[k] : p.zero;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(next + 4 * at), 16, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < WG_ZI; ++k) {
+                    const int at = wave * 64 + k * WG_THREADS;
+                    if (at < n_z) {
+                        const bool ok = z_off[k] >= 0 && nb + (z_smp[k] & 4095) < s_hi;
+                        const float* src = ok ? (z_smp[k] >= 4096 ? zb1 : zb0) + z_off[k] : p.zero;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(next + zs_at + 4 * at), 16, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < WG_GI; ++k) {
+                    const int i = tid + k * WG_THREADS;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < n_g) {
+                        const int row = i / GQ, q = i % GQ;
+                        const int smp = nb + (row >> p.lg_shift), l = row & (Lg - 1);
+                        if (smp < s_hi) v = wg_load4(p.G + (long)(smp * Lg + l) * p.ldg, m0 + 4 * q, p.M, gvec);
+                    }
+                    gr[k] = v;
+                }
+#pragma unroll
+                for (int k = 0; k < WG_ZI; ++k) {
+                    const int i = tid + k * WG_THREADS;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < n_z) {
+                        const int row = i / ZQ, q = i % ZQ;
+                        const int sl = row / SEGZ, pz = row - sl * SEGZ - p.pad;
+                        const int smp = nb + sl, c = c0 + 4 * q;
+                        if (smp < s_hi && pz >= 0 && pz < Lz && c < Ctot) {
+                            if (c < p.C0) v = wg_load4(p.Z0 + (long)(smp * Lz + pz) * p.ldz0, c, p.C0, z0vec);
+                            else v = wg_load4(p.Z1 + (long)(smp * Lz + pz) * p.ldz1, c - p.C0, p.C1, z1vec);
+                        }
+                    }
+                    zr[k] = v;
+                }
+            }
         }
+        if (sb >= s_lo) {
+            const float* const stage = smem + cur * stage_floats;
+            // two steps per round on two register sets, each set's LDS reads issued a whole step ahead of its
+            // MFMAs (hipcc otherwise sinks the reads to their use: one LDS round trip exposed per step)
+            float a0, z0[TAPS], a1, z1[TAPS];
+            frag(stage, s_first, a0, z0);
+            for (int s = s_first; s < s_last; s += 2) {
+                frag(stage, s + 1, a1, z1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < WG_ZI; ++k) {
-            const int i = tid + k * WG_THREADS;
-            if (i < n_z) *reinterpret_cast<float4*>(Zs + 4 * i) = zr[k];
+                for (int t = 0; t < TAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, z0[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                frag(stage, min(s + 2, s_last), a0, z0);     // (the last round re-reads a step it does not use)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, z1[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __syncthreads();
-        if (sb + spc < s_hi) chunk_load(sb + spc);           // in flight under the MFMAs below
-        // Two steps per round on two register sets, each set's LDS reads issued a whole step ahead of its MFMAs
-        // (hipcc otherwise sinks the reads to their use: one LDS round trip exposed per step).
-        float a0, z0[TAPS], a1, z1[TAPS];
-        frag(s_first, a0, z0);
-        for (int s = s_first; s < s_last; s += 2) {          // (host: an even number of steps per K-group)
-            frag(s + 1, a1, z1);
-            __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!ALIGNED) {
+            if (nb < s_hi) {
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, z0[t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            frag(min(s + 2, s_last), a0, z0);                // (the last round re-reads a step it does not use)
-            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < WG_GI; ++k) {
+                    const int i = tid + k * WG_THREADS;
+                    if (i < n_g) *reinterpret_cast<float4*>(next + 4 * i) = gr[k];
+                }
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, z1[t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < WG_ZI; ++k) {
+                    const int i = tid + k * WG_THREADS;
+                    if (i < n_z) *reinterpret_cast<float4*>(next + zs_at + 4 * i) = zr[k];
+                }
+            }
         }
+        __syncthreads();                 // the fetched chunk has landed (the barrier's fence drains the LDS-DMA); stage cur is free
+#ifdef DAD_WG_STAMPS
+        if (chunk_no < 24) WG_STAMP(1 + chunk_no);
+        ++chunk_no;
+#endif
     }
     // ---- the K-groups meet: groups [half, 2 half) park their accumulators, groups [0, half) add them
     if constexpr (KG > 1) {
-        __syncthreads();                                     // staging LDS is free
 #pragma unroll
-        for (int half = KG / 2; half >= 1; half >>= 1) {
+        for (int half = KG / 2; half >= 1; half >>= 1) {     // (the loop's last barrier freed the staging LDS)
             if (kg >= half && kg < 2 * half) {
                 float* dst = smem + ((kg - half) * NT + wt) * (TAPS * 16 * 64) + lane;
 #pragma unroll
@@ -197,6 +282,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
             }
             if (half > 1) __syncthreads();
         }
+        WG_STAMP(28);
         if (kg != 0) return;
     }
     // ---- store: D row = m (first operand), column = c
@@ -211,6 +297,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad(const WgradParams p) {
             for (int t = 0; t < TAPS; ++t) out[((long)m * Ctot + c) * TAPS + t] = acc[t][r];
         }
     }
+    WG_STAMP(29);
 }
 
 // ------------------------------------------------------------------ device-side weight re-packing
