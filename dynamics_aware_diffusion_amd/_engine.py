@@ -82,6 +82,7 @@ ABI = {
     "dad_debug_read_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.POINTER(C.c_int32)]),
     "dad_debug_mish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dad_debug_kernel_table_consistent": (C.c_int, []),
     "dad_debug_small_batch_plan": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                              C.POINTER(C.c_int32)]),
     "dad_model_set_training": (C.c_int, [C.c_void_p, C.c_int32]),

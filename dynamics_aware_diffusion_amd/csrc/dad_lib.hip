@@ -1499,6 +1499,26 @@ int dad_fill_normal(float* x, int32_t batch, int32_t row_elems, uint64_t seed, u
 #ifdef DAD_STAMPS
 int dad_debug_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return DAD_OK; }
 #endif
+// 1 when the host's statement of which conv-GEMM kernels exist (kernel_registered) equals the registry
+int dad_debug_kernel_table_consistent(void) {
+    const KernTable& t = kernel_table();
+    size_t hits = 0;
+    for (int cfg = 0; cfg < kNumTiles; ++cfg)
+        for (int taps = 1; taps <= 7; ++taps)
+            for (int stride = 1; stride <= 2; ++stride)
+                for (int f = 0; f < 16; ++f) {
+                    const bool x3 = f & 1, bdir = f & 2, ragged = f & 4, res = f & 8;
+                    const bool have = t.count(KernKey(cfg, taps, stride, x3, bdir, ragged, res)) != 0;
+                    if (have != kernel_registered(cfg, taps, stride, x3, bdir, ragged, res)) {
+                        fail(DAD_E_INVALID, "kernel table mismatch at tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d (registry %d)",
+                             cfg, taps, stride, (int)x3, (int)bdir, (int)ragged, (int)res, (int)have);
+                        return 0;
+                    }
+                    hits += have;
+                }
+    return hits == t.size() ? 1 : 0;
+}
+
 #ifdef DAD_WG_STAMPS
 extern "C" int dad_debug_wgrad_stamps(unsigned long long* host32) {
     HIP_TRY(hipDeviceSynchronize());

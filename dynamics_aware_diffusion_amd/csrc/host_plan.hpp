@@ -245,7 +245,7 @@ inline void decide_kernel_families(HostModel* m) {
         op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
                 (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
                  ((op.kind == CONV_K5 && op.taps == 5) || op.kind == CONV_1X1 ||
-                  ((op.cin0 & 63) == 0 && (cin_all & 63) == 0)));
+                  ((op.kind == CONV_DOWN || op.kind == CONV_UP) && (op.cin0 & 63) == 0 && (cin_all & 63) == 0)));
     }
 }
 
@@ -830,6 +830,22 @@ inline bool fused_at(const HostModel& m, const ConvOp& op, int batch) {
                sizeof(float) <= dad::kLdsBytes;
 }
 
+// Which conv-GEMM instantiations exist (the registry of dad_lib.hip, reg_tile, restated on the host so that the
+// planner — and the sanitizer harness, which has no device code — refuses a launch no kernel was compiled for;
+// dad_debug_kernel_table_consistent() compares the two).
+inline bool kernel_registered(int cfg, int taps, int stride, bool x3, bool bdir, bool ragged, bool res) {
+    if (cfg < 0 || cfg >= kNumTiles) return false;
+    const bool kc16 = kTiles[cfg].KC >= 16;
+    const bool k357 = taps == 3 || taps == 5 || taps == 7;
+    if (ragged && !(stride == 1 && (k357 || taps == 1) && !bdir)) return false;
+    if (bdir) return !kc16 && !res && !ragged && stride == 1 && k357;
+    if (res) return kc16 && !x3 && stride == 1 && k357;
+    if (x3) return kc16 && ((taps == 5 && stride == 1) || (taps == 3 && stride == 2) || (taps == 2 && stride == 1) ||
+                            (taps == 1 && stride == 1));
+    if (stride == 2) return taps == 3 || (taps == 5 && kc16);
+    return stride == 1 && (taps == 1 || taps == 2 || k357);
+}
+
 inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g) {
     if ((long)batch * op.Lout * op.M >= (1L << 31) ||
         (long)batch * op.Lin * (op.cin0 + op.cin1) >= (1L << 31))
@@ -857,6 +873,9 @@ inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g)
     if (op.cin_pad % g.kc != 0 && !g.ragged)
         return fail(DAD_E_INVALID, "%s: padded channel count %d is not a multiple of the K chunk %d",
                     op.name.c_str(), op.cin_pad, g.kc);
+    if (!kernel_registered(g.cfg, op.taps, op.stride, op.x3, op.bdir, g.ragged, g.fused))
+        return fail(DAD_E_INVALID, "no kernel for %s (tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d)",
+                    op.name.c_str(), g.cfg, op.taps, op.stride, (int)op.x3, (int)op.bdir, (int)g.ragged, (int)g.fused);
     g.threads = 64 * (t.BM / 32) * (t.BN / 32) * t.SK;
     g.lds_bytes = dad::conv_lds_floats(t.BM, t.BN, g.kc, op.taps, op.Lin, op.Lout, t.SK, op.bdir,
                                        op.taps + (g.fused ? 1 : 0)) * sizeof(float);

@@ -293,6 +293,8 @@ int dad_debug_set_option(dad_model* m, const char* name, int32_t value);
 int dad_debug_read_table(dad_model* m, int32_t which, int32_t t, float* host_out, int32_t capacity,
                          int32_t* width_out);
 int dad_debug_mish(const float* in, float* out, int64_t n, dad_stream_t stream);
+/* 1 when the planner's statement of which conv-GEMM kernels exist equals the kernel registry (no device call) */
+int dad_debug_kernel_table_consistent(void);
 /* Which kernels a batch takes (host-side query, no device work): launches_out = conv launches of one
  * denoiser evaluation through the small-batch consumer-combine kernels (csrc/conv_cc.hpp), 0 when the
  * batch runs the batch-256 kernels; wide_out = how many of them are the streamed-weight form for

@@ -74,6 +74,16 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == -1
 
 
+def test_planner_and_kernel_registry_agree():
+    """The planner refuses launches no kernel was compiled for from its own statement of the registry
+    (csrc/host_plan.hpp kernel_registered — what the sanitizer harness checks launch plans against); the two
+    must be the same set (round 3: a 3-tap conv under the split-f16 arithmetic was planned onto a kernel that
+    does not exist)."""
+    from dynamics_aware_diffusion_amd import _engine
+    lib = _engine.load_library()
+    assert lib.dad_debug_kernel_table_consistent() == 1, lib.dad_last_error()
+
+
 def _pointmaze_cfg():
     from dynamics_aware_diffusion_amd import _engine
     cfg = _engine.DadCfg()
