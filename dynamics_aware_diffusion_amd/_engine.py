@@ -58,6 +58,7 @@ ABI = {
     "dad_model_load_schedule": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     "dad_model_load_time_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "dad_model_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "dad_model_set_group_channels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     "dad_model_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t)]),
     "dad_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -183,12 +184,29 @@ class HipEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a ROCm device; there is no CPU path")
+        # widths the tiles cannot hold (not a multiple of 32 with a power-of-two C / 8) run zero-padded:
+        # utils/padding.py builds the padded tensors, the library is told the real widths
+        from .utils import padding
+        self.real_dim, self.real_channels = int(dim), [int(c) for c in channels]
+        padded = [padding.padded_width(c) for c in self.real_channels]
+        self.padded = padded != self.real_channels
+        if self.padded:
+            if self.real_channels[0] != self.real_dim:
+                raise NotImplementedError("zero-padded widths need dim_mults[0] == 1")
+            if transition_dim == self.real_dim:
+                raise NotImplementedError(
+                    f"transition_dim == dim == {dim} makes the first block's residual the trajectory itself; "
+                    "with zero-padded GroupNorm groups that identity has no kernel")
+            if training:
+                raise NotImplementedError(
+                    f"level widths {self.real_channels} run on zero-padded GroupNorm groups (inference only): "
+                    "train with widths that are a multiple of 32 with a power-of-two C / 8")
         cfg = DadCfg()
         cfg.transition_dim = transition_dim
-        cfg.dim = dim
+        cfg.dim = padded[0] if self.padded else dim
         cfg.time_dim = time_dim or dim
         cfg.n_levels = len(channels)
-        for i, ch in enumerate(channels):
+        for i, ch in enumerate(padded):
             cfg.channels[i] = int(ch)
         cfg.kernel_size = kernel_size
         cfg.horizon = horizon
@@ -203,6 +221,9 @@ class HipEngine:
         _check(self.lib, self.lib.dad_model_create(C.byref(cfg), C.byref(handle)))
         self._h = handle
         _check(self.lib, self.lib.dad_model_set_precision(self._h, PRECISIONS[precision]))
+        if self.padded:
+            real = (C.c_int32 * len(self.real_channels))(*self.real_channels)
+            _check(self.lib, self.lib.dad_model_set_group_channels(self._h, real, len(self.real_channels)))
         self.training = bool(training)
         if self.training:
             _check(self.lib, self.lib.dad_model_set_training(self._h, 1))
@@ -224,6 +245,10 @@ class HipEngine:
              schedule: Mapping[str, torch.Tensor]) -> None:
         """Upload every denoiser tensor (reference state_dict keys without ``model.``) and
         the five schedule buffers, then build tables and the launch plan."""
+        if self.padded:
+            from .utils import padding
+            mults = [c // self.real_dim for c in self.real_channels]
+            unet_state, _, _ = padding.pad_unet_state(unet_state, self.transition_dim, self.real_dim, mults)
         keep = []
         for key, t in unet_state.items():
             h = t.detach().to("cpu", torch.float32).contiguous()
@@ -239,7 +264,11 @@ class HipEngine:
                                  f"{self.n_timesteps}")
             bufs.append(b)
         _check(self.lib, self.lib.dad_model_load_schedule(self._h, *[b.data_ptr() for b in bufs]))
-        emb = sinusoid_table(self.n_timesteps, int(self.cfg.dim))
+        emb = sinusoid_table(self.n_timesteps, self.real_dim)
+        if self.padded:                    # the real columns in front, as time_mlp.1.weight is padded
+            wide = torch.zeros(self.n_timesteps, int(self.cfg.dim))
+            wide[:, :self.real_dim] = emb
+            emb = wide.contiguous()
         _check(self.lib, self.lib.dad_model_load_time_embedding(
             self._h, emb.data_ptr(), self.n_timesteps, int(self.cfg.dim)))
         with torch.cuda.device(self.device):

@@ -102,6 +102,8 @@ struct ConvParams {
     int32_t cin_pad;     // (cin0+cin1) rounded up to KC
     int32_t M;           // GEMM columns (2*C_out for the transposed conv)
     int32_t cpg;         // channels per GroupNorm group (M/8) when gamma != nullptr
+    int32_t cpg_real;    // > 0: only the first cpg_real channels of every group exist (dad_model_set_group_channels:
+                         // the rest are zero padding and do not count in the statistics); 0: all of them
     int32_t B;           // batch rows in this call
     int32_t Lin, Lout;   // per-sample input / output length of the GEMM
     int32_t lshift;      // log2(Lout)
@@ -820,7 +822,8 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     }
 
     if (has_gn) {
-        const float inv_cnt = 1.0f / (float)(cnt4 * 4);
+        const int creal = p.cpg_real > 0 ? p.cpg_real : cpg;        // channels of a group that exist
+        const float inv_cnt = 1.0f / (float)(Lout * creal);          // (= cnt4 * 4 without padding)
         const int width = lpp < 64 ? lpp : 64;
         const int wpp = lpp >> 6;                      // waves per pair when a pair spans waves
         auto pair_sum = [&](float v, int slot) -> float {
@@ -845,10 +848,19 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         for (int k = 0; k < F4PL; ++k) sum += (y[k][0] + y[k][1]) + (y[k][2] + y[k][3]);
         const float mean = pair_sum(sum, 0) * inv_cnt;
         float sq = 0.0f;
+        if (p.cpg_real > 0) {                          // (block-uniform) padded groups: the zero channels hold
+#pragma unroll                                          // conv + bias = 0 exactly — nothing for the sum, masked here
+            for (int k = 0; k < F4PL; ++k) {
+                const int cl = ecol[k] & (cpg - 1);    // channel of the float4 inside its group
 #pragma unroll
-        for (int k = 0; k < F4PL; ++k)
+                for (int c = 0; c < 4; ++c) { const float d = cl + c < creal ? y[k][c] - mean : 0.0f; sq += d * d; }
+            }
+        } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float d = y[k][c] - mean; sq += d * d; }
+            for (int k = 0; k < F4PL; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float d = y[k][c] - mean; sq += d * d; }
+        }
         const float rstd = 1.0f / sqrtf(pair_sum(sq, 1) * inv_cnt + 1e-5f);
         if (p.stats != nullptr && lp == 0 && eoff[0] >= 0) {      // one lane per (sample, group) pair
             float* st = p.stats + ((long)(s0 + ps) * (M >> (31 - __clz(cpg))) + ((m0 >> (31 - __clz(cpg))) + pg)) * 2;

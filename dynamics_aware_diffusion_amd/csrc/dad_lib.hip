@@ -349,7 +349,7 @@ int launch_conv(dad_model* m, const ConvOp& op, int batch, const ConvIO& io, hip
     p.dst = io.dst;
     p.pre = io.pre; p.stats = io.stats;
     p.cin0 = op.cin0; p.cin1 = op.cin1; p.cin_pad = op.cin_pad;
-    p.M = op.M; p.cpg = op.norm.empty() ? 0 : op.cout / 8;
+    p.M = op.M; p.cpg = op.norm.empty() ? 0 : op.cout / 8; p.cpg_real = op.gn_real;
     p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout; p.lshift = ilog2(op.Lout);
     p.lshift_in = ilog2(op.Lin);
     p.interleave = op.kind == CONV_UP;
@@ -776,6 +776,22 @@ int dad_model_set_precision(dad_model* m, int32_t precision) {
     if (precision != m->precision) m->finalized = false;       // weights must be re-packed
     m->precision = precision;
     decide_kernel_families(m);
+    return DAD_OK;
+}
+
+int dad_model_set_group_channels(dad_model* m, const int32_t* real_channels, int32_t n_levels) {
+    if (!m || !real_channels) return fail(DAD_E_INVALID, "null argument");
+    if (n_levels != m->cfg.n_levels) return fail(DAD_E_INVALID, "%d levels given, the model has %d", n_levels, m->cfg.n_levels);
+    for (int i = 0; i < n_levels; ++i) {
+        const int real = real_channels[i], padded = m->cfg.channels[i];
+        if (real < 8 || real % 8 != 0 || real > padded)
+            return fail(DAD_E_INVALID, "level %d: %d real channels in %d (need a multiple of 8, at most the padded width)", i, real, padded);
+    }
+    for (int i = 0; i < DAD_MAX_LEVELS; ++i) m->real_channels[i] = i < n_levels ? real_channels[i] : 0;
+    const int rc = build_plan(m);                 // the same plan; every GroupNorm'd conv now knows its real group width
+    if (rc != DAD_OK) return rc;
+    m->finalized = false;
+    if (m->training) if (const char* why = training_refusal(*m)) return fail(DAD_E_INVALID, "training: %s", why);
     return DAD_OK;
 }
 

@@ -73,6 +73,7 @@ struct ConvOp {
     // GroupNorm'd conv — its pre-normalisation output (conv + bias) and the (mean, rstd) of every
     // (sample, group) pair, [8][2] floats per sample
     int pre = -1, stats = -1;
+    int gn_real = 0;         // > 0: channels per GroupNorm group that exist (the rest of the group is zero padding)
     // device tensors (owned by the model)
     float* d_w = nullptr;
     float* d_bias = nullptr;
@@ -151,6 +152,7 @@ struct HostModel {
                                                                //   for the five launches it replaces
     int chain_min_batch = 64;                                  //   from this batch on (one block per sample: below, the
                                                                //   chip is mostly idle and the batch kernels' split-K wins)
+    int real_channels[DAD_MAX_LEVELS] = {0};                   // dad_model_set_group_channels: widths before padding (0: as cfg)
     int wgrad_blocks = 256;                                    // blocks a weight-gradient launch aims for (tiles x batch splits)
     bool ccw_prefer16 = true;                                  //   two 16-row tiles instead of an LDS-short 32-row one
                                                                //   (measured crossover: batch 16 at H = 32)
@@ -259,11 +261,14 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
     const int tdm = c.time_dim;
     int temb_off = 0;
 
+    int level_now = 0;               // level whose width the convs being emitted produce
     auto conv = [&](const std::string& name, const std::string& norm, ConvKind kind, int src0,
                     int src1, int cin0, int cin1, int cout, int Lin, int dst, int res,
                     int toff) {
         ConvOp op;
         op.name = name; op.norm = norm; op.kind = kind;
+        const int real = m->real_channels[level_now];
+        if (!norm.empty() && real > 0 && real != cout) op.gn_real = real / 8;
         op.cin0 = cin0; op.cin1 = cin1;
         op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
         const int padto = op.kc == 8 ? 8 : (kind == CONV_1X1 ? 128 : 64);   // deepest K chunk of its kernels
@@ -294,9 +299,15 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
         P.convs.push_back(op);
     };
 
+    // widths before zero-padding (dad_model_set_group_channels): which blocks have a residual conv is a property of
+    // the REAL widths (40 / 80 / 120 channels run as 64 / 128 / 128: the 80 -> 120 block keeps its 1x1 conv)
+    auto realw = [&](int level) { return m->real_channels[level] > 0 ? m->real_channels[level] : c.channels[level]; };
+    bool padded_net = false;
+    for (int i = 0; i < c.n_levels; ++i) padded_net = padded_net || realw(i) != c.channels[i];
+    const char* plan_error = nullptr;
     auto res_block = [&](const std::string& base, int in0, int in1, int cin0, int cin1, int cout,
-                         int L) -> int {
-        const int cin = cin0 + cin1;
+                         int L, int rcin, int rcout) -> int {
+        const int cin = padded_net ? (rcin == rcout ? cout : cout + 1) : cin0 + cin1;   // only compared with cout below
         const int toff = temb_off;
         temb_off += cout;
         expect(m, base + ".time_mlp.1.weight", {cout, tdm});
@@ -306,6 +317,8 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
              cout, L, a0, -1, toff);
         int res = -1;
         const bool cat_identity = cin == cout && in1 >= 0;   // nn.Identity over torch.cat([x, skip])
+        if (cat_identity && padded_net)
+            plan_error = "an identity residual over a channel concat (shrinking dim_mults) with zero-padded GroupNorm groups";
         if (cin != cout) {
             res = A.get((long)cout * L);
             const int c0 = (int)P.convs.size() - 1;
@@ -341,10 +354,11 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
     std::vector<int> skips, skip_ch;
     for (int i = 0; i < nl; ++i) {
         const int co = c.channels[i];
+        level_now = i;
         const std::string b = "downs." + std::to_string(i);
-        const int h1 = res_block(b + ".0", x, -1, cx, 0, co, L);
+        const int h1 = res_block(b + ".0", x, -1, cx, 0, co, L, i == 0 ? c.transition_dim : realw(i - 1), realw(i));
         if (x >= 0) A.put(x);
-        const int h2 = res_block(b + ".1", h1, -1, co, 0, co, L);
+        const int h2 = res_block(b + ".1", h1, -1, co, 0, co, L, realw(i), realw(i));
         A.put(h1);
         skips.push_back(h2);
         skip_ch.push_back(co);
@@ -360,8 +374,9 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
         cx = co;
     }
     const int cm = c.channels[nl - 1];
-    const int m1 = res_block("mid_block1", x, -1, cm, 0, cm, L);
-    const int m2 = res_block("mid_block2", m1, -1, cm, 0, cm, L);
+    level_now = nl - 1;
+    const int m1 = res_block("mid_block1", x, -1, cm, 0, cm, L, realw(nl - 1), realw(nl - 1));
+    const int m2 = res_block("mid_block2", m1, -1, cm, 0, cm, L, realw(nl - 1), realw(nl - 1));
     A.put(m1);
     x = m2;
     cx = cm;
@@ -370,11 +385,12 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
         const int skip = skips[lvl];
         const int cs = skip_ch[lvl];
         const int co = c.channels[lvl - 1];
+        level_now = lvl - 1;
         const std::string b = "ups." + std::to_string(j);
-        const int u1 = res_block(b + ".0", x, skip, cx, cs, co, L);
+        const int u1 = res_block(b + ".0", x, skip, cx, cs, co, L, (j == 0 ? realw(nl - 1) : realw(lvl)) + realw(lvl), realw(lvl - 1));
         A.put(x);
         A.put(skip);
-        const int u2 = res_block(b + ".1", u1, -1, co, 0, co, L);
+        const int u2 = res_block(b + ".1", u1, -1, co, 0, co, L, realw(lvl - 1), realw(lvl - 1));
         A.put(u1);
         const int up = A.get((long)co * (2 * L));
         conv(b + ".2.conv", "", CONV_UP, u2, -1, co, 0, co, L, up, -1, -1);
@@ -383,10 +399,12 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
         x = up;
         cx = co;
     }
+    if (plan_error != nullptr) return fail(DAD_E_INVALID, "%s", plan_error);
     if (cx != c.dim)
         return fail(DAD_E_INVALID, "final_conv expects %d channels but the decoder ends with %d "
                     "(reference requires dim_mults[0] == 1)", c.dim, cx);
     const int f = A.get((long)c.dim * L);
+    level_now = 0;
     conv("final_conv.0.block.0", "final_conv.0.block.1", CONV_K5, x, -1, cx, 0, c.dim, L, f, -1, -1);
     P.final_act = f;
     expect(m, "final_conv.1.weight", {c.transition_dim, c.dim, 1});
@@ -477,6 +495,8 @@ inline int build_backward_plan(HostModel* m) {
 // Why a model cannot be trained on this engine, or nullptr.
 inline const char* training_refusal(const HostModel& m) {
     if (m.precision != DAD_PREC_FP32) return "the backward pass exists for the fp32 arithmetic only";
+    for (const ConvOp& op : m.tplan.convs)
+        if (op.gn_real > 0) return "widths that are not a multiple of 32 with a power-of-two C/8 run on zero-padded GroupNorm groups: inference only";
     for (const ConvOp& op : m.tplan.convs)
         if (op.cat0 >= 0) return "identity residual over a channel concat (shrinking dim_mults) has no backward kernel";
     return nullptr;
@@ -959,6 +979,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 32 || c.kernel_size != 5 ||
         (long)batch * c.horizon > m.cc_max_rows)
         return refuse(P, "disabled, split-f16 arithmetic, horizon > 32, kernel_size != 5 or more than cc_max_rows rows");
+    for (const ConvOp& op : convs)
+        if (op.gn_real > 0) return refuse(P, "zero-padded GroupNorm groups (dad_model_set_group_channels): batch kernels only");
     for (const ConvOp& op : convs)      // weight images in 16-channel granules only
         if ((op.kc != 16 && !op.bdir) || op.cat0 >= 0 || op.x3 || (!op.rname.empty() && !op.ride)) return refuse(P, "a weight image not in 16-channel granules, or an identity residual over a concat");
     P.ops.resize(convs.size());
@@ -1127,7 +1149,7 @@ inline ChainPlan chain_plan(const HostModel& m) {
           v[4].res == v[3].src0 && v[5].kind == CONV_DOWN && v[5].src0 == v[4].dst))
         return P;
     for (int i : {0, 2, 3, 4, 5})
-        if (v[i].cout != C || v[i].kc != 16 || v[i].x3 || v[i].bdir) return P;
+        if (v[i].cout != C || v[i].kc != 16 || v[i].x3 || v[i].bdir || v[i].gn_real > 0) return P;
     P.ok = true; P.last = 5; P.C = C;
     return P;
 }

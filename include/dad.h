@@ -104,6 +104,14 @@ int dad_model_load_time_embedding(dad_model* m, const float* emb, int32_t n_time
  * dad_model_finalize (weights are re-packed); a finalized model must be finalized again. */
 int dad_model_set_precision(dad_model* m, int32_t precision);
 
+/* Widths the reference accepts and the conv-GEMM tiles do not — GroupNorm(8, C) needs only C % 8 == 0
+ * (temporal_unet.py:71: `--dim 48`, `--dim 96`), the tiles a multiple of 32 with a power-of-two C / 8: the host
+ * language pads every GroupNorm group of such a level with zero channels up to the next power of two >= 4 (weights,
+ * biases, gamma / beta of the padding are zero: the padded net computes the same function), gives the PADDED widths
+ * in dad_cfg and states the real ones here; the GroupNorm statistics then count the real channels only.  Call
+ * between dad_model_create and dad_model_finalize.  Such models run the batch kernels at every batch size and are
+ * refused by dad_model_set_training. */
+int dad_model_set_group_channels(dad_model* m, const int32_t* real_channels, int32_t n_levels);
 /* Checks every tensor is present, builds the per-timestep time-embedding tables
  * (SinusoidalPosEmb + time_mlp + every block's Mish->Linear, temporal_unet.py:19-32,
  * 97-100,155-160 — batch-invariant during sampling) and the launch plan. */

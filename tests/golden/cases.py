@@ -97,6 +97,10 @@ NETS = {
     # TemporalUnet(kernel_size=3 / 7) (temporal_unet.py:139; see KERNEL_SIZES)
     "tiny_k3": (4, 2, 32, (1, 2, 4), 20, 9, 0.25),
     "tiny_k7": (5, 3, 64, (1, 2), 20, 10, 0.25),
+    # widths GroupNorm(8, C) accepts and the conv tiles do not (temporal_unet.py:71: only C % 8 == 0 is needed):
+    # 48 / 96 channels -> groups of 6 / 12, 24 / 48 / 96 -> 3 / 6 / 12; the engine runs them zero-padded
+    "tiny_d48": (4, 2, 48, (1, 2), 20, 11, 0.25),
+    "tiny_d24": (5, 3, 24, (1, 2, 4), 20, 12, 0.25),
 }
 
 # (case, net, B, t)  — single U-Net forward
@@ -108,6 +112,8 @@ FORWARD_CASES = [
     ("fwd_door", "door_j", 2, 999),
     ("fwd_tiny_k3", "tiny_k3", 3, 11),
     ("fwd_tiny_k7", "tiny_k7", 5, 2),
+    ("fwd_tiny_d48", "tiny_d48", 3, 9),
+    ("fwd_tiny_d24", "tiny_d24", 6, 15),
 ]
 
 # (case, net, T_train, n_sample_steps, B, conditioned, schedule)
@@ -120,6 +126,7 @@ LOOP_CASES = [
     ("loop_tiny4_T20_B3_cond", "tiny4", 20, 20, 3, True, "cosine"),
     ("loop_pointmaze_T100_B4_cond", "pointmaze", 100, 100, 4, True, "cosine"),
     ("loop_pointmaze_T100_B1_cond", "pointmaze", 100, 100, 1, True, "cosine"),   # get_action's B=1 plan
+    ("loop_tiny_d48_T20_B3_cond", "tiny_d48", 20, 20, 3, True, "cosine"),        # zero-padded GroupNorm groups
 ]
 
 # The T=1000 loops of BASELINE configs 4 and 5 (two plans each; the reference takes minutes on

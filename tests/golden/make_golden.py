@@ -198,6 +198,8 @@ def gen_forward(only_small: bool = False):
 
 def gen_loops():
     for case, net, T, n_steps, B, conditioned, schedule in cases.LOOP_CASES:
+        if CASE_FILTER and case not in CASE_FILTER:
+            continue
         print(f"  loop {case} ...")
         diff = build_reference(net, T, schedule)
         diff.n_timesteps = n_steps                     # evaluate.py:350-353 semantics
@@ -534,7 +536,7 @@ SECTIONS = {
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
-    ap.add_argument("--cases", default="", help="comma-separated fixture names (forward / grads sections)")
+    ap.add_argument("--cases", default="", help="comma-separated fixture names (forward / loops / grads sections)")
     args = ap.parse_args()
     CASE_FILTER.update(c for c in args.cases.split(",") if c)
     torch.manual_seed(0)

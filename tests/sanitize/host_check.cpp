@@ -30,6 +30,7 @@ struct Arch {
     std::vector<int> mults;
     bool pack;      // also load synthetic weights and build the packed images
     int ks = 5;     // TemporalUnet(kernel_size): 3, 5 or 7
+    std::vector<int> real = {};   // dad_model_set_group_channels: level widths before zero-padding the groups
 };
 
 static float synth(uint64_t& state) {       // cheap deterministic values in (-1, 1)
@@ -67,8 +68,18 @@ static void check_arch(const Arch& a, int precision) {
     m.precision = precision;               // (build_plan decides the kernel families from it)
     int rc = check_cfg(&c);
     if (rc != DAD_OK) { printf("  %-14s refused: %s\n", a.name, g_err); return; }
+    for (size_t i = 0; i < a.real.size(); ++i) m.real_channels[i] = a.real[i];
     rc = build_plan(&m);
     if (rc != DAD_OK) { printf("  %-14s refused: %s\n", a.name, g_err); return; }
+    if (!a.real.empty()) {
+        int padded_ops = 0;
+        for (const ConvOp& op : m.plan.convs) {
+            if (op.gn_real > 0) { ++padded_ops; CHECK(!op.norm.empty() && op.gn_real < op.cout / 8, "%s: gn_real %d of %d", op.name.c_str(), op.gn_real, op.cout / 8); }
+        }
+        CHECK(padded_ops > 0, "no conv knows its real group width");
+        CHECK(training_refusal(m) != nullptr, "padded groups accepted for training");
+        CHECK(!cc_plan(m, 1).ok, "padded groups took the small-batch kernels");
+    }
     const Plan& P = m.plan;
     CHECK(P.final_act >= 0 && P.final_act < (int)P.bufs.size(), "final_act %d", P.final_act);
 
@@ -384,6 +395,8 @@ int main(int argc, char** argv) {
         {"wide_k7", 9, 256, 256, 16, {1, 8}, false, 7},
         {"h128_k7", 6, 128, 128, 128, {1, 2}, true, 7},
         {"shrink_k7", 5, 32, 32, 32, {1, 4, 2}, true, 7},
+        {"d48_padded", 6, 64, 48, 32, {1, 2}, true, 5, {48, 96}},          // --dim 48 as the engine runs it
+        {"d40_padded", 5, 64, 40, 32, {1, 2, 2}, true, 5, {40, 80, 120}},   // 40 / 80 / 120 -> 64 / 128 / 128
     };
     // the fuzz generator's space (tests/fuzz_parity.py), deterministic sweep
     std::mt19937 rng(7);

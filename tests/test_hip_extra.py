@@ -561,6 +561,12 @@ def test_graph_replay_with_inkernel_noise(dev):
     (11, 32, (1, 2), 16, 1, 7),        #   ... batch 1 (the small-batch kernels are 5-tap only: batch kernels + split-K)
     (23, 256, (1, 4, 8), 32, 4, 3),    # kernel_size=3 on the HalfCheetah widths (LDS-staged <256,32> tile at 2048 channels)
     (5, 32, (1, 4, 2), 32, 3, 7),      # kernel_size=7 with an identity residual over the concat
+    (6, 48, (1, 2), 32, 5),            # --dim 48: GroupNorm groups of 6 / 12 channels (temporal_unet.py:71 needs only
+    (9, 96, (1, 2, 4), 16, 70),        #   C % 8 == 0) run zero-padded to 8 / 16 (utils/padding.py,
+    (6, 24, (1, 2, 4), 32, 130),       #   dad_model_set_group_channels): masked GroupNorm statistics in the epilogue;
+    (5, 40, (1, 2, 3), 32, 2),         #   40 / 80 / 120 -> 64 / 128 / 128: two levels share a padded width
+    (7, 8, (1, 2), 16, 1),             #   one-channel groups (dim 8) at batch 1: split-K + padding
+    (6, 48, (1, 2), 32, 9, 3),         #   ... with kernel_size 3
 ], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}" + (f"_k{a[5]}" if len(a) > 5 else ""))
 def test_assorted_architectures_match_oracle(arch, dev):
     """Shapes outside the three BASELINE architectures, against the oracle on seeded inputs."""
@@ -681,12 +687,12 @@ def test_unsupported_architectures_are_refused_with_a_message(dev):
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
     from dynamics_aware_diffusion_amd._engine import DadError
     for kwargs, H in ((dict(dim=32, dim_mults=(1, 2, 4, 8)), 16),     # 16 / 8 = 2 < 4
-                      (dict(dim=48, dim_mults=(1, 2)), 32),           # C/8 = 6 not a power of two
+                      (dict(dim=44, dim_mults=(1, 2)), 32),           # GroupNorm(8, 44) does not exist in the reference either
                       (dict(dim=32, dim_mults=(1, 2), kernel_size=4), 32),   # even kernel: the reference's padding k//2 changes the length
                       (dict(dim=32, dim_mults=(1, 2), kernel_size=9), 32)):
         unet = TemporalUnet(6, **kwargs)
         diff = GaussianDiffusion(unet, H, 4, 2, n_timesteps=10).to(dev)
-        with pytest.raises(DadError):
+        with pytest.raises((DadError, ValueError)):
             diff.model(torch.zeros(1, H, 6, device=dev), 0)
 
 

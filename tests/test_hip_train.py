@@ -150,6 +150,12 @@ def test_training_refusals(dev):
             diff.model(torch.zeros(2, cases.H, 6, device=dev), torch.zeros(2, dtype=torch.long, device=dev))
     finally:
         diff.model.precision = "fp32"
+    # zero-padded GroupNorm groups (widths that are not a multiple of 32 with a power-of-two C / 8): inference only
+    padded = build("tiny_d48", 20, "cosine", dev)
+    with torch.enable_grad(), pytest.raises(NotImplementedError, match="zero-padded"):
+        padded.model(torch.zeros(2, cases.H, 6, device=dev), torch.zeros(2, dtype=torch.long, device=dev))
+    with torch.no_grad():
+        assert padded.model(torch.zeros(2, cases.H, 6, device=dev), 3).shape == (2, cases.H, 6)
 
 
 def test_sgd_steps_track_the_oracle_without_leaving_the_device(dev):

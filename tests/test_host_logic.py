@@ -74,6 +74,57 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == -1
 
 
+def test_zero_padded_groups_keep_every_real_weight():
+    """utils/padding.py: a --dim 48 net (GroupNorm groups of 6 / 12 channels) becomes a 64 / 128-channel net whose
+    extra channels are zero; every real entry sits where channel_index says, and the padded shapes are what the
+    library expects for the padded widths (dad_model_load_weight checks them against its own plan)."""
+    import ctypes as C
+    from dynamics_aware_diffusion_amd import _engine
+    from dynamics_aware_diffusion_amd.utils import padding, synth
+    assert [padding.padded_width(c) for c in (8, 24, 32, 48, 64, 96, 120, 128, 2048)] == [32, 32, 32, 64, 64, 128, 128, 128, 2048]
+    with pytest.raises(ValueError):
+        padding.padded_width(44)
+    idx = padding.channel_index(48)
+    assert idx.tolist()[:7] == [0, 1, 2, 3, 4, 5, 8] and int(idx[-1]) == 7 * 8 + 5
+    td, dim, mults = 6, 48, (1, 2)
+    state = {k: torch.from_numpy(v) for k, v in synth.synth_unet_state(td, dim, mults, seed=2, affine_jitter=0.2).items()}
+    padded, pdim, widths = padding.pad_unet_state(state, td, dim, mults)
+    assert pdim == 64 and widths == [64, 128] and set(padded) == set(state)
+    i48, i96 = padding.channel_index(48), padding.channel_index(96)
+    w = padded["downs.1.0.blocks.0.block.0.weight"]                      # Conv1d(48 -> 96, k5)
+    assert tuple(w.shape) == (128, 64, 5)
+    assert torch.equal(w[i96][:, i48], state["downs.1.0.blocks.0.block.0.weight"])
+    assert int(w.count_nonzero()) == int(state["downs.1.0.blocks.0.block.0.weight"].count_nonzero())
+    u = padded["ups.0.0.blocks.0.block.0.weight"]                        # Conv1d(cat[96 | 96] -> 48)
+    assert tuple(u.shape) == (64, 256, 5)
+    assert torch.equal(u[i48][:, torch.cat([i96, 128 + i96])], state["ups.0.0.blocks.0.block.0.weight"])
+    t = padded["ups.0.2.conv.weight"]                                    # ConvTranspose1d(48, 48): (in, out, k)
+    assert torch.equal(t[i48][:, i48], state["ups.0.2.conv.weight"])
+    g = padded["final_conv.0.block.1.weight"]
+    assert torch.equal(g[i48], state["final_conv.0.block.1.weight"]) and int(g.count_nonzero()) == 48
+    assert tuple(padded["final_conv.1.weight"].shape) == (td, 64, 1) and tuple(padded["time_mlp.1.weight"].shape) == (4 * 48, 64)
+    # the library's own expectations for the padded widths
+    lib = _engine.load_library()
+    cfg = _engine.DadCfg()
+    cfg.transition_dim, cfg.dim, cfg.time_dim, cfg.n_levels = td, 64, 48, 2
+    cfg.channels[0], cfg.channels[1] = 64, 128
+    cfg.kernel_size, cfg.horizon, cfg.n_timesteps = 5, 32, 10
+    cfg.predict_epsilon = cfg.clip_denoised = 1
+    h = C.c_void_p()
+    assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == 0
+    real = (C.c_int32 * 2)(48, 96)
+    assert lib.dad_model_set_group_channels(h, real, 2) == 0
+    for key, v in padded.items():
+        v = v.contiguous()
+        shape = (C.c_int64 * v.dim())(*v.shape)
+        assert lib.dad_model_load_weight(h, key.encode(), v.data_ptr(), shape, v.dim()) == 0, (key, lib.dad_last_error())
+    assert lib.dad_model_set_training(h, 1) == -1 and b"padd" in lib.dad_last_error()
+    bad = (C.c_int32 * 2)(44, 96)
+    assert lib.dad_model_set_group_channels(h, bad, 2) == -1
+    assert lib.dad_model_set_group_channels(h, real, 3) == -1
+    lib.dad_model_destroy(h)
+
+
 def test_planner_and_kernel_registry_agree():
     """The planner refuses launches no kernel was compiled for from its own statement of the registry
     (csrc/host_plan.hpp kernel_registered — what the sanitizer harness checks launch plans against); the two

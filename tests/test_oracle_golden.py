@@ -53,7 +53,7 @@ def test_unit_layers(case):
     assert max_abs(y.numpy(), g[name]) <= TOL
 
 
-@pytest.mark.parametrize("case", [c for c in cases.FORWARD_CASES if c[1] in ("tiny", "tiny4", "pointmaze_j", "tiny_k3", "tiny_k7")],
+@pytest.mark.parametrize("case", [c for c in cases.FORWARD_CASES if c[1] in ("tiny", "tiny4", "pointmaze_j", "tiny_k3", "tiny_k7", "tiny_d48", "tiny_d24")],
                          ids=lambda c: c[0])
 def test_unet_forward(case):
     name, net, B, t = case
