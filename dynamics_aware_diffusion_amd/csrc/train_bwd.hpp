@@ -357,6 +357,62 @@ __global__ void repack_kernel(const RepackParams p) {
     p.dst[d] = v;
 }
 
+// Every image of a refresh in ONE launch: descriptor table + block ranges in device memory (cached by the caller
+// while the parameter tensors keep their addresses), block b finds its descriptor by bisection over first[].
+__global__ __launch_bounds__(256) void repack_many_kernel(const RepackParams* descs, const int* first, int ndesc) {
+    int lo = 0, hi = ndesc - 1;                  // first[lo] <= blockIdx.x < first[lo + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const RepackParams p = descs[lo];
+    const long d = (long)((int)blockIdx.x - first[lo]) * 256 + threadIdx.x;
+    if (d >= p.n) return;
+    const int j = (int)(d % p.kg);
+    long r = d / p.kg;
+    const int o = (int)(r % p.M);
+    r /= p.M;
+    const int slot = (int)(r % p.wtaps);
+    const int ci = (int)(r / p.wtaps) * p.kg + j;
+    float v = 0.0f;
+    switch (p.mode) {
+        case RP_FWD:
+            if (ci < p.CI) {
+                if (slot < p.K) v = p.w[((long)o * p.CI + ci) * p.K + slot];
+                else if (p.ride != nullptr) v = p.ride[(long)o * p.CI + ci];
+            }
+            break;
+        case RP_FWD_UP: case RP_BWD_DOWN: {
+            const int co = p.M >> 1, half = o >= co, oo = o - half * co;
+            const int kk = half == 0 ? (slot == 0 ? 3 : 1) : (slot == 0 ? 2 : 0);
+            if (p.mode == RP_FWD_UP) { if (ci < p.CI) v = p.w[((long)ci * co + oo) * 4 + kk]; }
+            else if (ci < p.CO && kk < 3) v = p.w[((long)ci * p.CI + oo) * 3 + kk];
+            break;
+        }
+        case RP_BWD_CONV:
+            if (o < p.c_n && ci < p.CO) v = p.w[((long)ci * p.CI + p.c_lo + o) * p.K + (p.K - 1 - slot)];
+            break;
+        case RP_BWD_UP:
+            if (slot >= 1 && o < p.CI && ci < p.CO) v = p.w[((long)o * p.CO + ci) * 4 + (slot - 1)];
+            break;
+        case RP_BWD_FINAL:
+            if (ci < p.CO) v = p.w[(long)ci * p.CI + o];
+            break;
+    }
+    p.dst[d] = v;
+}
+
+// The small tensors of a refresh (biases, GroupNorm parameters, time-MLP tensors) in one launch: blockIdx.y picks
+// the copy, descriptors travel as kernel arguments.
+constexpr int COPY_MAX = 150;
+struct CopyMany { float* dst[COPY_MAX]; const float* src[COPY_MAX]; int32_t n[COPY_MAX]; };
+__global__ __launch_bounds__(256) void copy_many_kernel(const CopyMany a) {
+    const int n = a.n[blockIdx.y];
+    const float* src = a.src[blockIdx.y];
+    float* dst = a.dst[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // out[i] = sum_k slab[k][i].  Thread (i, g) of a block adds slabs g, g + 4, g + 8, ... of float4 i (four loads in
 // flight per thread, four times the threads of a one-thread-per-element loop: a level-0 conv of PointMaze has 64
 // slabs of 82 k floats), the four partial sums meet in LDS and are added in group order — fixed order, no atomics.

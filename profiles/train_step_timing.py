@@ -57,7 +57,23 @@ for _ in range(N):
     diff.loss(x0).backward()
 torch.cuda.synchronize()
 steady = (time.perf_counter() - t0) / N
+# the same with an optimiser step in the loop: every parameter changes, so the next forward re-derives the engine's
+# packed copies on the device (dad_model_refresh_weights) — the cost this design adds to a training step
+opt = torch.optim.SGD(diff.parameters(), lr=1e-5)
+for _ in range(2):
+    opt.zero_grad(set_to_none=True)
+    diff.loss(x0).backward()
+    opt.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    opt.zero_grad(set_to_none=True)
+    diff.loss(x0).backward()
+    opt.step()
+torch.cuda.synchronize()
+steady_opt = (time.perf_counter() - t0) / N
 fm, bm = min(fwd) * 1e3, min(bwd) * 1e3
 print(f"{args.arch} B={args.batch}: training forward {fm:.2f} ms ({f / fm / 1e9:.1f} TFLOP/s), backward {bm:.2f} ms "
       f"({2 * f / bm / 1e9:.1f} TFLOP/s algorithmic), {N} steps back to back {steady * 1e3:.2f} ms per step "
-      f"({3 * f / steady / 1e12:.1f} TFLOP/s, {args.batch / steady:.0f} samples/s), loss {float(loss):.5f}", flush=True)
+      f"({3 * f / steady / 1e12:.1f} TFLOP/s, {args.batch / steady:.0f} samples/s), with SGD step + weight refresh "
+      f"{steady_opt * 1e3:.2f} ms per step ({args.batch / steady_opt:.0f} samples/s), loss {float(loss):.5f}", flush=True)
