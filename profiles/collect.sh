@@ -15,7 +15,7 @@ root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out/profiles_$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-stamp="$(date +%H%M%S)"
+stamp="$(date +%m%d%H%M%S)"
 
 run_pass() {   # name, limit seconds, command...
   local name="$1" limit="$2"; shift 2

@@ -23,7 +23,7 @@ def one(pattern):
     import re
     head = pattern.split("/")[0]
     assert head.endswith("_*"), pattern
-    want = re.compile("^" + re.escape(head[:-2]) + r"_(\d{6})$")
+    want = re.compile("^" + re.escape(head[:-2]) + r"_(\d{6,10})$")
     hits = []
     for f in glob.glob(os.path.join(src, pattern), recursive=True):
         m = want.match(os.path.relpath(f, src).split(os.sep)[0])
