@@ -112,10 +112,14 @@ constexpr int CC_MAX_PAIR = CC_F4 * 4 * 64;
 // BIG: tensors with 9..16 partial slabs (1024-channel inputs) add them in a second, dependent batch
 // of loads; a kernel-level template parameter, so that the common kernels keep their register
 // budget (with both forms in one kernel the allocator spilled the staged weights).
+// Windowed tiles (layers of more than 32 positions: horizon 64 on the get_action path): the tile covers rows
+// [wl0, wl0 + seg - 2 pad) of ONE sample; the pair statistics still run over the whole sample, but only the rows
+// of the window and its halo go to LDS (at row l - wl0 + pad) and only the window's own rows are published.
+// wl0 < 0: whole samples per tile (every row is staged at smp * seg + pad + l).
 template <bool RIDE, bool BIG>
 __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
                                                   int L, int lshiftL, int seg, int pad, int c0, int nch,
-                                                  bool publish, int lane, int wave) {
+                                                  bool publish, int lane, int wave, int wl0 = -1) {
     const int cpg = s.cpg;
     const int groups = nch / cpg;                           // whole groups (host guarantees)
     const int nsmp = nrows_valid >> lshiftL;
@@ -130,6 +134,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
         float4 v[CC_F4], ex[CC_F4], gam[CC_F4], bet[CC_F4];
         long off[CC_F4];
         int lo[CC_F4];
+        unsigned onmask = 0, pubmask = 0;              // bit k: float4 k belongs to the pair / is published by this tile
         CC_GN_STAMP(8);
 #pragma unroll
         for (int k = 0; k < CC_F4; ++k) {
@@ -143,7 +148,15 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
             const int l = jj / cq, cl = (jj - l * cq) * 4;
             const int c = c0 + g * cpg + cl;
             off[k] = (long)(r0 + smp * L + l) * s.C + c;
-            lo[k] = on ? (smp * seg + pad + l) * ld + g * cpg + cl : -1;
+            if (wl0 < 0) {
+                lo[k] = on ? (smp * seg + pad + l) * ld + g * cpg + cl : -1;
+                if (on) pubmask |= 1u << k;
+            } else {
+                const int wr = l - wl0 + pad;          // row of the window stage
+                lo[k] = (on && wr >= 0 && wr < seg) ? wr * ld + g * cpg + cl : -1;
+                if (on && wr >= pad && wr < seg - pad) pubmask |= 1u << k;
+            }
+            if (on) onmask |= 1u << k;
             // every load below is unconditional (lanes past the pair re-read element 0; slabs that do
             // not exist re-read the last one and are not added): they all fly together
             // (absent operands re-read something valid and are masked afterwards: a load under a
@@ -223,7 +236,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
         float sq = 0.0f;
 #pragma unroll
         for (int k = 0; k < CC_F4; ++k)
-            if (lo[k] >= 0) {
+            if (onmask >> k & 1) {
                 const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
                 sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
@@ -238,7 +251,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
             y.z = mish_fast_f32((v[k].z - mean) * rstd * gam[k].z + bet[k].z) + ex[k].z;
             y.w = mish_fast_f32((v[k].w - mean) * rstd * gam[k].w + bet[k].w) + ex[k].w;
             *reinterpret_cast<float4*>(dst + lo[k]) = y;
-            if (publish && s.mat != nullptr) *reinterpret_cast<float4*>(s.mat + off[k]) = y;
+            if (publish && s.mat != nullptr && (pubmask >> k & 1)) *reinterpret_cast<float4*>(s.mat + off[k]) = y;
         }
         CC_GN_STAMP(11);
     }
@@ -253,11 +266,60 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
 template <bool BIG>
 __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
                                                int nrows_tile, int L, int lshiftL, int seg, int pad, int c0,
-                                               int nch, bool publish, int tid, int lane, int wave) {
+                                               int nch, bool publish, int tid, int lane, int wave, int wl0 = -1) {
     const int q4 = nch >> 2;
     const long sstride = (long)s.rows * s.C;
     const bool plain = s.nsl == 0;
     const bool gn = !plain && s.gamma != nullptr;
+    if (wl0 >= 0) {
+        // windowed tile: ONE sample (rows r0 .. r0 + L), stage rows [wl0 - pad, wl0 + seg - pad) of it; the caller
+        // zeroed the stage (rows of the halo that fall outside the sample stay zero)
+        if (gn) {
+            if (s.rslab != nullptr) cc_build_input_gn<true, BIG>(s, dst, ld, r0, L, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, wl0);
+            else cc_build_input_gn<false, BIG>(s, dst, ld, r0, L, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, wl0);
+            __syncthreads();
+            return;
+        }
+        for (int i = tid; i < seg * q4; i += CC_THREADS) {
+            const int wr = i / q4, q = i - wr * q4;
+            const int l = wl0 - pad + wr;
+            const int c = c0 + 4 * q;
+            if (l < 0 || l >= L || c >= s.C) continue;
+            const long off = (long)(r0 + l) * s.C + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (plain) {
+                if ((s.C & 3) == 0) {
+                    v = ldg4(s.data + off);
+                } else {                                    // external trajectory: C = transition_dim
+                    const float* g = s.data + off;
+                    const int left = s.C - c;
+                    v.x = g[0];
+                    if (left > 1) v.y = g[1];
+                    if (left > 2) v.z = g[2];
+                    if (left > 3) v.w = g[3];
+                }
+            } else {
+                float4 part[CC_MAX_SLABS];
+#pragma unroll
+                for (int k = 0; k < CC_MAX_SLABS; ++k)
+                    part[k] = ldg4(s.data + (long)min(k, s.nsl - 1) * sstride + off);
+                v = part[0];
+#pragma unroll
+                for (int k = 1; k < CC_MAX_SLABS; ++k)
+                    if (k < s.nsl) { v.x += part[k].x; v.y += part[k].y; v.z += part[k].z; v.w += part[k].w; }
+                for (int k = CC_MAX_SLABS; k < s.nsl; ++k) {
+                    const float4 u = ldg4(s.data + (long)k * sstride + off);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                const float4 b = ldg4(s.bias + c);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                if (publish && s.mat != nullptr && wr >= pad && wr < seg - pad) *reinterpret_cast<float4*>(s.mat + off) = v;
+            }
+            *reinterpret_cast<float4*>(dst + wr * ld + 4 * q) = v;
+        }
+        __syncthreads();
+        return;
+    }
     // zero halo rows (LDS only)
     if (pad > 0) {
         const int nsmp = nrows_tile >> lshiftL;
@@ -330,9 +392,8 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
 // LDS floats of one conv_cc block: [X rows][slice + 4] + [weight taps][32][slice + 4], or the
 // exchange tile [8 waves][32][36] (+ the ride's) after the K loop.
 __host__ __device__ inline size_t cc_lds_floats(int slice_ch, int taps, int wtaps, int Lin, int Lout, int nr) {
-    const int spt = nr / Lout;
     const size_t xs = slice_ch + 4;
-    const size_t k = (size_t)spt * (Lin + 2 * (taps / 2)) * xs + (size_t)wtaps * 32 * xs;
+    const size_t k = (size_t)cc_xrows(taps, Lin, Lout, nr) * xs + (size_t)wtaps * 32 * xs;
     const size_t e = (size_t)2 * 8 * nr * 36;
     return k > e ? k : e;
 }
@@ -364,10 +425,14 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     const int l32 = lane & 31, h = lane >> 5;
     const int kb = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
     const int Lin = p.Lin, Lout = p.Lout, M = p.M;
-    const int SPT = NR >> p.lshift;                    // whole samples per tile
-    const int SEG = Lin + 2 * PAD;
+    // windowed tiles (stride-1 layers of more than NR positions): tile nt = rows [wl0, wl0 + NR) of sample nt / tps
+    const bool WIN = Lout > NR;
+    const int tps = WIN ? Lout / NR : 1;
+    const int wl0 = WIN ? (nt % tps) * NR : -1;
+    const int SPT = WIN ? 1 : NR >> p.lshift;          // whole samples per tile
+    const int SEG = WIN ? NR + 2 * PAD : Lin + 2 * PAD;
     const int XROWS = SPT * SEG;
-    const int s0 = nt * SPT;
+    const int s0 = WIN ? nt / tps : nt * SPT;
     const int nvalid = min(SPT, p.B - s0);
     const int m0 = mt * 32;
     const int SL = p.slice_ch;
@@ -403,12 +468,12 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     const int cs0 = second ? c0 - p.cin0 : c0;         // first channel inside that source
     const int cin_src = second ? p.cin1 : p.cin0;
     const int nch = min(SL, ((cin_src - cs0) + 3) & ~3);   // channels to stage (rest of the slice: zero)
-    if (nch < SL) {                                    // zero the columns the staging leaves untouched
+    if (nch < SL || WIN) {                             // zero the columns / halo rows the staging leaves untouched
         for (int i = tid; i < XROWS * XS4; i += CC_THREADS) smem4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
     cc_build_input<BIG>(src, Xb, XS, s0 * Lin, nvalid * Lin, SPT * Lin, Lin, p.lshift_in, SEG, PAD, cs0, nch,
-                        mt == 0, tid, lane, wave);
+                        mt == 0, tid, lane, wave, wl0);
     CC_STAMP(2);
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
@@ -431,6 +496,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
         f32x16 acc, acc2, acc3, acc4, accr, accr2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; acc4[r] = 0.f; accr[r] = 0.f; accr2[r] = 0.f; }
+        // (windowed tile: l32 >> lshift = 0 and l32 & (Lout - 1) = l32 — the window's rows in order)
         const int arow4 = (((l32 >> p.lshift) * SEG + (l32 & (Lout - 1)) * STRIDE + phase_shift) * XS + 4 * h) >> 2;
         const int brow4 = (XROWS * XS + l32 * XS + 4 * h) >> 2;
         const int G = SL >> 3;                         // 8-channel groups in the slice
@@ -540,7 +606,7 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
         const float4 u = *reinterpret_cast<const float4*>(q + w * NR * ES);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
-    const int smp = row >> p.lshift, l = row & (Lout - 1);
+    const int smp = row >> p.lshift, l = (row & (Lout - 1)) + (WIN ? wl0 : 0);
     if (smp >= nvalid) return;
     const int em = m0 + col;
     long off;

@@ -32,6 +32,12 @@ DAD_HD inline size_t conv_lds_floats(int BM, int BN, int KC, int taps, int Lin, 
     return k > epi ? k : epi;
 }
 
+// conv_cc.hpp: rows of a block's X stage — whole samples with their zero halo, or (layers of more than `nr`
+// positions: windowed tiles) `nr` rows of one sample plus the halo on both sides.
+DAD_HD inline int cc_xrows(int taps, int Lin, int Lout, int nr) {
+    return Lout > nr ? nr + 2 * (taps / 2) : (nr / Lout) * (Lin + 2 * (taps / 2));
+}
+
 // conv_ccw.hpp (wide small-batch convs).  K phase: X rows with halo [XROWS][slice + 4], the additive
 // terms [rows][slice + 4], gamma / beta [2][slice], pair statistics; afterwards the exchange tile.
 constexpr int kCcwMaxPairs = 64;         // (sample, group) pairs of one block's input slice

@@ -976,9 +976,13 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     CcPlan P;
     const dad_cfg& c = m.cfg;
     const std::vector<ConvOp>& convs = m.plan.convs;
-    if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 32 || c.kernel_size != 5 ||
+    if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 128 || c.kernel_size != 5 ||
         (long)batch * c.horizon > m.cc_max_rows)
-        return refuse(P, "disabled, split-f16 arithmetic, horizon > 32, kernel_size != 5 or more than cc_max_rows rows");
+        return refuse(P, "disabled, split-f16 arithmetic, horizon > 128, kernel_size != 5 or more than cc_max_rows rows");
+    // horizons beyond 32 (windowed tiles): measured on the PointMaze net at horizon 64 — 276 / 279 / 294 us per denoise
+    // step at batch 1 / 2 / 4 against 281 / 293 / 314 on the batch kernels, 409 against 345 at batch 8
+    if (c.horizon > 32 && (long)batch * c.horizon > 256)
+        return refuse(P, "horizon > 32 and more than 256 rows");
     for (const ConvOp& op : convs)
         if (op.gn_real > 0) return refuse(P, "zero-padded GroupNorm groups (dad_model_set_group_channels): batch kernels only");
     for (const ConvOp& op : convs)      // weight images in 16-channel granules only
@@ -1004,7 +1008,11 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
             return true;
         };
         if (!input(op.src0, o.in0) || !input(op.src1, o.in1)) return refuse(P, "input with no known producer");
-        if (op.M % 32 != 0 || 32 % op.Lout != 0 || op.Lout > 32) return refuse(P, "output columns not a multiple of 32, or a length that does not divide 32");
+        // layers of more than 32 positions (horizon 64 / 128): windowed tiles — 32 rows of one sample per tile,
+        // stride-1 5-tap convs of conv_cc only (the pair statistics still span the sample: <= 1024 elements)
+        const bool windowed = op.Lout > 32;
+        if (op.M % 32 != 0 || (!windowed && 32 % op.Lout != 0) || (windowed && (op.Lout % 32 != 0 || op.kind != CONV_K5)))
+            return refuse(P, "output columns not a multiple of 32, a length that does not divide 32, or a long layer that is not a stride-1 conv");
         // K slices: whole GroupNorm groups of the tensor being finished
         const int cin = op.cin0 + op.cin1;
         int need = 32, max_slabs_in = 0;
@@ -1027,6 +1035,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         // conv_cc keeps the whole weight slice in LDS and normalises a pair in one wave's registers;
         // anything wider goes to conv_ccw (weights streamed global -> registers)
         o.wide = slice > kCcMaxSlice || max_pair > 1024 || op.bdir || op.kind == CONV_1X1;   // (conv_cc has no 1x1 form)
+        if (o.wide && (windowed || op.Lin > 32)) return refuse(P, "a wide layer (conv_ccw) of more than 32 positions");
         if (!o.wide) {
             if (slice % 32 != 0) return refuse(P, "K slice not a multiple of 32 channels");
             // 16-row tiles (16x16x4 MFMAs, half the padded rows) as long as the layer still fits one wave
@@ -1084,8 +1093,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         // a (sample, group) pair of the output is normalised by its consumer: conv_cc / final_cc take at
         // most 1024 elements per pair, conv_ccw 8192 (checked again where the consumer is planned)
         if (!op.norm.empty() && (long)(op.cout / 8) * op.Lout > kCcwMaxPair) return refuse(P, "GroupNorm pair above 8192 elements");
-        const int spt = o.tile_rows / op.Lout;
-        o.ntiles = (batch + spt - 1) / spt;
+        const int spt = windowed ? 1 : o.tile_rows / op.Lout;
+        o.ntiles = windowed ? batch * (op.Lout / 32) : (batch + spt - 1) / spt;
         o.out_rows = op.kind == CONV_UP ? batch * 2 * op.Lout : batch * op.Lout;
         o.out_cols = op.kind == CONV_UP ? op.M / 2 : op.M;
         o.oslab = off;
@@ -1096,7 +1105,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         } else {
             // the exchange tile needs 2 * 8 * 32 * 36 floats; operands XROWS + weight rows of slice + 4
             const size_t xs = slice + 4;
-            const size_t k = (size_t)spt * (op.Lin + 2 * (op.taps / 2)) * xs + (size_t)op.wtaps() * 32 * xs;
+            const size_t k = (size_t)dad::cc_xrows(op.taps, op.Lin, op.Lout, o.tile_rows) * xs + (size_t)op.wtaps() * 32 * xs;
             const size_t e = (size_t)2 * 8 * o.tile_rows * 36;
             o.lds_bytes = std::max(k, e) * sizeof(float);
         }

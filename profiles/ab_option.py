@@ -26,6 +26,7 @@ ap.add_argument("--values", required=True)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--repeats", type=int, default=5)
 ap.add_argument("--graph", type=int, default=1)
+ap.add_argument("--horizon", type=int, default=32)
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -33,7 +34,7 @@ od, ad, dim, mults, T = synth.ARCHS[args.arch]
 td = od + ad
 unet = TemporalUnet(td, dim=dim, dim_mults=mults)
 unet.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_unet_state(td, dim, mults, seed=0).items()})
-diff = GaussianDiffusion(unet, 32, od, ad, n_timesteps=T).to(dev)
+diff = GaussianDiffusion(unet, args.horizon, od, ad, n_timesteps=T).to(dev)
 diff.sampler_rng, diff.seed, diff.use_graph = "philox", 1, bool(args.graph)
 diff.n_timesteps = min(T, args.steps)
 cond = torch.zeros(1, td)

@@ -255,8 +255,16 @@ static void check_arch(const Arch& a, int precision) {
                 CHECK((size_t)(o.slice_ch / 16) * op.wtaps() * 128 <= (size_t)6 * 512, "%s: weight staging registers", op.name.c_str());
                 CHECK(o.kslices <= 8 || o.slice_ch == kCcMaxSlice, "%s: more than 8 slabs below the widest slice", op.name.c_str());
             }
-            CHECK((o.tile_rows == 16 || o.tile_rows == 32) && o.tile_rows % op.Lout == 0 &&
-                  o.ntiles * (o.tile_rows / op.Lout) >= B, "%s: tiles do not cover the batch", op.name.c_str());
+            if (op.Lout > 32) {           // windowed tiles: 32 rows of one sample each, stride-1 k-tap convs of conv_cc only
+                CHECK(!o.wide && op.kind == CONV_K5 && op.stride == 1 && o.tile_rows == 32 && op.Lout % 32 == 0 &&
+                      o.ntiles == B * (op.Lout / 32), "%s: windowed tiles", op.name.c_str());
+                CHECK(o.lds_bytes >= ((size_t)(32 + 2 * (op.taps / 2)) * (o.slice_ch + 4) + (size_t)op.wtaps() * 32 * (o.slice_ch + 4)) * sizeof(float),
+                      "%s: windowed LDS", op.name.c_str());
+            } else {
+                CHECK((o.tile_rows == 16 || o.tile_rows == 32) && o.tile_rows % op.Lout == 0 &&
+                      o.ntiles * (o.tile_rows / op.Lout) >= B, "%s: tiles do not cover the batch", op.name.c_str());
+            }
+            if (o.wide) CHECK(op.Lin <= 32 && op.Lout <= 32, "%s: conv_ccw beyond 32 positions", op.name.c_str());
             const long n = (long)o.kslices * o.out_rows * o.out_cols;
             spans.push_back({o.oslab, o.oslab + n});
             if (o.orslab >= 0) spans.push_back({o.orslab, o.orslab + n});
@@ -273,7 +281,7 @@ static void check_arch(const Arch& a, int precision) {
                     if (qo.res_kind == 4) CHECK(cc.ops[qo.res_ride].launched && P.convs[qo.res_ride].kind == CONV_1X1 && qo.res_ride < in->producer,
                                                 "%s: residual conv source", op.name.c_str());
                     const long pair = q.norm.empty() ? 0 : (long)(q.cout / 8) * op.Lin;
-                    const int spt = o.tile_rows / op.Lout;
+                    const int spt = op.Lout > 32 ? 1 : o.tile_rows / op.Lout;
                     if (o.wide) {
                         CHECK(qo.kslices <= kCcwMaxSlabs && (qo.res_kind < 3 || cc.ops[qo.res_ride].kslices <= kCcwMaxSlabs),
                               "%s: wide conv fed more than %d slabs", op.name.c_str(), kCcwMaxSlabs);
