@@ -116,10 +116,14 @@ constexpr int CC_MAX_PAIR = CC_F4 * 4 * 64;
 // [wl0, wl0 + seg - 2 pad) of ONE sample; the pair statistics still run over the whole sample, but only the rows
 // of the window and its halo go to LDS (at row l - wl0 + pad) and only the window's own rows are published.
 // wl0 < 0: whole samples per tile (every row is staged at smp * seg + pad + l).
-template <bool RIDE, bool BIG>
+// WINOK: the kernel can be launched with windowed tiles at all (5-tap stride-1 convs on 32-row tiles with at most 8
+// input slabs); elsewhere wl0 is -1 at compile time and none of this costs a register (the 9..16-slab variants sit
+// at 253 VGPRs).
+template <bool RIDE, bool BIG, bool WINOK>
 __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
                                                   int L, int lshiftL, int seg, int pad, int c0, int nch,
-                                                  bool publish, int lane, int wave, int wl0 = -1) {
+                                                  bool publish, int lane, int wave, int wl0_arg) {
+    const int wl0 = WINOK ? wl0_arg : -1;
     const int cpg = s.cpg;
     const int groups = nch / cpg;                           // whole groups (host guarantees)
     const int nsmp = nrows_valid >> lshiftL;
@@ -263,10 +267,11 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
 // nch is a multiple of 4 except for the ragged external trajectory (C = transition_dim), whose
 // channels beyond C read as zero.  All threads of the block take part; ends with a barrier.
 // `publish`: also store the finished values to s.mat.
-template <bool BIG>
+template <bool BIG, bool WINOK = false>
 __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int ld, int r0, int nrows_valid,
                                                int nrows_tile, int L, int lshiftL, int seg, int pad, int c0,
-                                               int nch, bool publish, int tid, int lane, int wave, int wl0 = -1) {
+                                               int nch, bool publish, int tid, int lane, int wave, int wl0_arg = -1) {
+    const int wl0 = WINOK ? wl0_arg : -1;
     const int q4 = nch >> 2;
     const long sstride = (long)s.rows * s.C;
     const bool plain = s.nsl == 0;
@@ -275,8 +280,8 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
         // windowed tile: ONE sample (rows r0 .. r0 + L), stage rows [wl0 - pad, wl0 + seg - pad) of it; the caller
         // zeroed the stage (rows of the halo that fall outside the sample stay zero)
         if (gn) {
-            if (s.rslab != nullptr) cc_build_input_gn<true, BIG>(s, dst, ld, r0, L, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, wl0);
-            else cc_build_input_gn<false, BIG>(s, dst, ld, r0, L, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, wl0);
+            if (s.rslab != nullptr) cc_build_input_gn<true, BIG, WINOK>(s, dst, ld, r0, L, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, wl0);
+            else cc_build_input_gn<false, BIG, WINOK>(s, dst, ld, r0, L, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, wl0);
             __syncthreads();
             return;
         }
@@ -339,8 +344,8 @@ __device__ __forceinline__ void cc_build_input(const CcSrc& s, float* dst, int l
             *reinterpret_cast<float4*>(dst + ((r >> lshiftL) * seg + pad + (r & (L - 1))) * ld + 4 * q) =
                 make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (s.rslab != nullptr) cc_build_input_gn<true, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
-        else cc_build_input_gn<false, BIG>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave);
+        if (s.rslab != nullptr) cc_build_input_gn<true, BIG, false>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, -1);
+        else cc_build_input_gn<false, BIG, false>(s, dst, ld, r0, nrows_valid, L, lshiftL, seg, pad, c0, nch, publish, lane, wave, -1);
         __syncthreads();
         return;
     }
@@ -426,7 +431,8 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     const int kb = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
     const int Lin = p.Lin, Lout = p.Lout, M = p.M;
     // windowed tiles (stride-1 layers of more than NR positions): tile nt = rows [wl0, wl0 + NR) of sample nt / tps
-    const bool WIN = Lout > NR;
+    constexpr bool WINOK = TAPS == 5 && STRIDE == 1 && NR == 32 && !BIG;
+    const bool WIN = WINOK && Lout > NR;
     const int tps = WIN ? Lout / NR : 1;
     const int wl0 = WIN ? (nt % tps) * NR : -1;
     const int SPT = WIN ? 1 : NR >> p.lshift;          // whole samples per tile
@@ -472,8 +478,8 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
         for (int i = tid; i < XROWS * XS4; i += CC_THREADS) smem4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
-    cc_build_input<BIG>(src, Xb, XS, s0 * Lin, nvalid * Lin, SPT * Lin, Lin, p.lshift_in, SEG, PAD, cs0, nch,
-                        mt == 0, tid, lane, wave, wl0);
+    cc_build_input<BIG, WINOK>(src, Xb, XS, s0 * Lin, nvalid * Lin, SPT * Lin, Lin, p.lshift_in, SEG, PAD, cs0, nch,
+                               mt == 0, tid, lane, wave, wl0);
     CC_STAMP(2);
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {

@@ -1036,6 +1036,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         // anything wider goes to conv_ccw (weights streamed global -> registers)
         o.wide = slice > kCcMaxSlice || max_pair > 1024 || op.bdir || op.kind == CONV_1X1;   // (conv_cc has no 1x1 form)
         if (o.wide && (windowed || op.Lin > 32)) return refuse(P, "a wide layer (conv_ccw) of more than 32 positions");
+        if (windowed && max_slabs_in > 8) return refuse(P, "a windowed layer fed more than 8 slabs");
         if (!o.wide) {
             if (slice % 32 != 0) return refuse(P, "K slice not a multiple of 32 channels");
             // 16-row tiles (16x16x4 MFMAs, half the padded rows) as long as the layer still fits one wave
