@@ -152,15 +152,14 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
             const int l = jj / cq, cl = (jj - l * cq) * 4;
             const int c = c0 + g * cpg + cl;
             off[k] = (long)(r0 + smp * L + l) * s.C + c;
-            if (wl0 < 0) {
-                lo[k] = on ? (smp * seg + pad + l) * ld + g * cpg + cl : -1;
-                if (on) pubmask |= 1u << k;
+            if constexpr (!WINOK) {
+                lo[k] = on ? (smp * seg + pad + l) * ld + g * cpg + cl : -1;     // (lo >= 0 <=> part of the pair)
             } else {
                 const int wr = l - wl0 + pad;          // row of the window stage
                 lo[k] = (on && wr >= 0 && wr < seg) ? wr * ld + g * cpg + cl : -1;
                 if (on && wr >= pad && wr < seg - pad) pubmask |= 1u << k;
+                if (on) onmask |= 1u << k;
             }
-            if (on) onmask |= 1u << k;
             // every load below is unconditional (lanes past the pair re-read element 0; slabs that do
             // not exist re-read the last one and are not added): they all fly together
             // (absent operands re-read something valid and are masked afterwards: a load under a
@@ -240,7 +239,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
         float sq = 0.0f;
 #pragma unroll
         for (int k = 0; k < CC_F4; ++k)
-            if (onmask >> k & 1) {
+            if (WINOK ? (onmask >> k & 1) != 0 : lo[k] >= 0) {
                 const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
                 sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
@@ -255,7 +254,7 @@ __device__ __forceinline__ void cc_build_input_gn(const CcSrc& s, float* dst, in
             y.z = mish_fast_f32((v[k].z - mean) * rstd * gam[k].z + bet[k].z) + ex[k].z;
             y.w = mish_fast_f32((v[k].w - mean) * rstd * gam[k].w + bet[k].w) + ex[k].w;
             *reinterpret_cast<float4*>(dst + lo[k]) = y;
-            if (publish && s.mat != nullptr && (pubmask >> k & 1)) *reinterpret_cast<float4*>(s.mat + off[k]) = y;
+            if (publish && s.mat != nullptr && (!WINOK || (pubmask >> k & 1))) *reinterpret_cast<float4*>(s.mat + off[k]) = y;
         }
         CC_GN_STAMP(11);
     }
@@ -412,9 +411,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // units of 16 channels — the same matrix-pipe cycles per unit for half the padded rows.
 // WPT: float4 of weights each thread stages = slice * weight taps * 32 rows / 4 / 512 threads, rounded
 // up: 6 covers the widest slice (64 channels, 6 taps).
-template <int TAPS, int STRIDE, bool RES, bool BIG, int NR, int WPT = 6>
+// WINDOWED: its own instantiation (layers of more than 32 positions), so that the kernels of the horizon-32 plans
+// stay exactly what they were (with the window logic as a runtime branch of one kernel the PointMaze batch-1 step
+// went from 211 to 224 us).
+template <int TAPS, int STRIDE, bool RES, bool BIG, int NR, int WPT = 6, bool WINDOWED = false>
 __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     static_assert(NR == 16 || NR == 32, "tile rows");
+    static_assert(!WINDOWED || (TAPS == 5 && STRIDE == 1 && NR == 32 && !BIG), "windowed tiles: 5-tap stride-1 convs, 32 rows, <= 8 slabs");
     constexpr int PAD = TAPS / 2;
     constexpr int WTAPS = TAPS + (RES ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -431,8 +434,8 @@ __global__ __launch_bounds__(CC_THREADS) void conv_cc(const CcParams p) {
     const int kb = blockIdx.x, mt = blockIdx.y, nt = blockIdx.z;
     const int Lin = p.Lin, Lout = p.Lout, M = p.M;
     // windowed tiles (stride-1 layers of more than NR positions): tile nt = rows [wl0, wl0 + NR) of sample nt / tps
-    constexpr bool WINOK = TAPS == 5 && STRIDE == 1 && NR == 32 && !BIG;
-    const bool WIN = WINOK && Lout > NR;
+    constexpr bool WINOK = WINDOWED;
+    constexpr bool WIN = WINDOWED;
     const int tps = WIN ? Lout / NR : 1;
     const int wl0 = WIN ? (nt % tps) * NR : -1;
     const int SPT = WIN ? 1 : NR >> p.lshift;          // whole samples per tile

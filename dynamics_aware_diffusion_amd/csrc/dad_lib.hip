@@ -211,7 +211,11 @@ const void* cc_kernel_t(int taps, bool ride) {
     if (taps == 2) return (const void*)dad::conv_cc<2, 1, false, BIG, NR>;
     return nullptr;
 }
-const void* cc_kernel(int taps, bool ride, bool big, int rows) {
+const void* cc_kernel(int taps, bool ride, bool big, int rows, bool windowed = false) {
+    if (windowed) {
+        if (taps != 5 || big || rows != 32) return nullptr;
+        return ride ? (const void*)dad::conv_cc<5, 1, true, false, 32, 6, true> : (const void*)dad::conv_cc<5, 1, false, false, 32, 6, true>;
+    }
     if (rows == 16) return big ? cc_kernel_t<true, 16>(taps, ride) : cc_kernel_t<false, 16>(taps, ride);
     return big ? cc_kernel_t<true, 32>(taps, ride) : cc_kernel_t<false, 32>(taps, ride);
 }
@@ -274,6 +278,8 @@ int configure_kernels() {
                 for (int rows : {16, 32})
                     if (const void* k = cc_kernel(taps, ride != 0, big != 0, rows))
                         HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
+    for (int ride = 0; ride < 2; ++ride)
+        HIP_TRY(hipFuncSetAttribute(cc_kernel(5, ride != 0, false, 32, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dad::kLdsBytes));
     for (int taps : {5, 3, 2, 1})
         for (int res = 0; res < 2; ++res)
             for (int ride = 0; ride < 2; ++ride)
@@ -467,7 +473,7 @@ int run_conv_cc(dad_model* m, const CcPlan& cc, int i, const float* xext, float*
     const bool shape_ok = (op.taps == 5 && op.stride == 1) || (op.taps == 3 && op.stride == 2) || (op.taps == 2 && op.stride == 1);
     const bool big = p.src0.nsl > dad::CC_MAX_SLABS || p.src0.nrs > dad::CC_MAX_SLABS ||
                      p.src1.nsl > dad::CC_MAX_SLABS || p.src1.nrs > dad::CC_MAX_SLABS;
-    const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, big, o.tile_rows) : nullptr;
+    const void* kern = shape_ok ? cc_kernel(op.taps, op.ride, big, o.tile_rows, op.Lout > 32) : nullptr;
     if (o.wide) {
         if (big) return fail(DAD_E_INVALID, "wide small-batch conv %s: more than %d partial slabs", op.name.c_str(), dad::CC_MAX_SLABS);
         kern = ccw_kernel(op.taps, op.ride, p.src0.rslab != nullptr || p.src1.rslab != nullptr, o.tile_rows);

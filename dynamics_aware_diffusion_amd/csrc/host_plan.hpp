@@ -979,8 +979,8 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
     if (m.precision != DAD_PREC_FP32 || !m.cc_enabled || c.horizon > 128 || c.kernel_size != 5 ||
         (long)batch * c.horizon > m.cc_max_rows)
         return refuse(P, "disabled, split-f16 arithmetic, horizon > 128, kernel_size != 5 or more than cc_max_rows rows");
-    // horizons beyond 32 (windowed tiles): measured on the PointMaze net at horizon 64 — 276 / 279 / 294 us per denoise
-    // step at batch 1 / 2 / 4 against 281 / 293 / 314 on the batch kernels, 409 against 345 at batch 8
+    // horizons beyond 32 (windowed tiles): measured on the PointMaze net at horizon 64 — 258 / 260 / 272 us per denoise
+    // step at batch 1 / 2 / 4 against 282 / 293 / 314 on the batch kernels; at batch 8 the batch kernels win
     if (c.horizon > 32 && (long)batch * c.horizon > 256)
         return refuse(P, "horizon > 32 and more than 256 rows");
     for (const ConvOp& op : convs)
