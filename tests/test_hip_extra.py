@@ -845,16 +845,18 @@ def test_config5_shards_equal_one_1024_row_run(dev):
         diff.sampler_rng = "torch"
 
 
-@pytest.mark.parametrize("arch", [(23, 32, (1, 4, 8), 17, 6), (8, 32, (1, 2, 4, 8), 5, 3)],
-                         ids=["mults_1_4_8", "mults_1_2_4_8"])
+@pytest.mark.parametrize("arch", [(23, 32, (1, 4, 8), 17, 6), (8, 32, (1, 2, 4, 8), 5, 3),
+                                  (6, 48, (1, 2), 4, 2, 3)],        # --dim 48 (zero-padded groups) with kernel_size 3
+                         ids=["mults_1_4_8", "mults_1_2_4_8", "dim48_k3"])
 def test_checkpoint_round_trip_on_the_device(arch, dev, tmp_path):
     """load_checkpoint(path) -> sampler on the GPU: the loaded net reproduces the oracle on the
     checkpoint's weights (raw and EMA), with widths inferred from shapes."""
     from dynamics_aware_diffusion_amd import load_checkpoint
     from dynamics_aware_diffusion_amd.utils import synth
     from tests.test_host_logic import _synthetic_checkpoint
-    td, dim, mults, od, ad = arch
-    ckpt, w, w_ema = _synthetic_checkpoint(td, dim, mults, od, ad, ema_seed=12)
+    td, dim, mults, od, ad = arch[:5]
+    ks = arch[5] if len(arch) > 5 else 5
+    ckpt, w, w_ema = _synthetic_checkpoint(td, dim, mults, od, ad, ema_seed=12, kernel_size=ks)
     path = tmp_path / "model.pt"
     torch.save(ckpt, path)
     x = torch.from_numpy(synth.normal_like(69, f"ckpt.{mults}", (3, 32, td)))
@@ -862,7 +864,7 @@ def test_checkpoint_round_trip_on_the_device(arch, dev, tmp_path):
     outs = []
     for use_ema, weights in ((False, w), (True, w_ema)):
         diff = load_checkpoint(path, device=dev, use_ema=use_ema)
-        assert diff.model.dim_mults == mults and diff.betas.device.type == "cuda"
+        assert diff.model.dim_mults == mults and diff.model.kernel_size == ks and diff.betas.device.type == "cuda"
         with torch.no_grad():
             want = orc.unet_forward({k: torch.from_numpy(v) for k, v in weights.items()}, x, t)
         got = diff.model(x.to(dev), 11)

@@ -309,14 +309,14 @@ def test_diffusion_attributes_and_errors():
 
 
 # ------------------------------------------------------------------------------ checkpoints
-def _synthetic_checkpoint(td, dim, mults, od, ad, T=20, horizon=32, time_dim=None, ema_seed=None):
+def _synthetic_checkpoint(td, dim, mults, od, ad, T=20, horizon=32, time_dim=None, ema_seed=None, kernel_size=5):
     """The dict the reference's trainer saves (utils/training.py:191-211), synthetic weights."""
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
     from dynamics_aware_diffusion_amd.utils import synth
 
     def state(seed):
-        unet = TemporalUnet(td, dim=dim, dim_mults=mults, time_dim=time_dim)
-        w = synth.synth_unet_state(td, dim, mults, seed=seed, affine_jitter=0.2, time_dim=time_dim)
+        unet = TemporalUnet(td, dim=dim, dim_mults=mults, time_dim=time_dim, kernel_size=kernel_size)
+        w = synth.synth_unet_state(td, dim, mults, seed=seed, affine_jitter=0.2, time_dim=time_dim, kernel_size=kernel_size)
         unet.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
         return GaussianDiffusion(unet, horizon, od, ad, n_timesteps=T).state_dict(), w
 
