@@ -59,6 +59,7 @@ ABI = {
     "dad_model_load_time_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "dad_model_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_model_set_group_channels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
+    "dad_model_set_horizon": (C.c_int, [C.c_void_p, C.c_int32]),
     "dad_model_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t)]),
     "dad_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
@@ -118,6 +119,8 @@ def load_library() -> C.CDLL:
             "(or __graft_entry__.build()).  There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in ABI.items():
+        if os.environ.get("DAD_LIB") and not hasattr(lib, name):
+            continue                       # an older timing-only build (A/B of two libraries on one box)
         fn = getattr(lib, name)            # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
@@ -201,15 +204,33 @@ class HipEngine:
                 raise NotImplementedError(
                     f"level widths {self.real_channels} run on zero-padded GroupNorm groups (inference only): "
                     "train with widths that are a multiple of 32 with a power-of-two C / 8")
+        # horizons every level can halve but that are not a power of two (24, 48, 96, 100 ...) run zero-padded to
+        # the next power of two (dad_model_set_horizon); the trajectory tensors keep their real shape
+        horizon = int(horizon)
+        levels = len(self.real_channels)
+        # (... and the deepest level keeps at least four padded positions, the tiles' lower bound: horizon 16 on four
+        # levels — 16 / 8 / 4 / 2 positions — runs in 32 / 16 / 8 / 4)
+        self.padded_horizon = max(1 << max(horizon - 1, 0).bit_length(), 4 << (levels - 1))
+        self.rows_padded = self.padded_horizon != horizon
+        if self.rows_padded:
+            if horizon % (1 << (levels - 1)) != 0:
+                raise ValueError(f"horizon {horizon} cannot be halved {levels - 1} times (the reference's U-Net needs "
+                                 f"H % 2^(levels-1) == 0, temporal_unet.py:35-54)")
+            if transition_dim == self.real_dim:
+                raise NotImplementedError("transition_dim == dim with a zero-padded horizon has no kernel")
+            if training:
+                raise NotImplementedError(f"horizon {horizon} runs zero-padded to {self.padded_horizon} (inference only): "
+                                          "train with a power-of-two horizon")
+        self.padded = self.padded or self.rows_padded      # (either kind: no training, no device-side refresh)
         cfg = DadCfg()
         cfg.transition_dim = transition_dim
-        cfg.dim = padded[0] if self.padded else dim
+        cfg.dim = padded[0] if padded != self.real_channels else dim
         cfg.time_dim = time_dim or dim
         cfg.n_levels = len(channels)
         for i, ch in enumerate(padded):
             cfg.channels[i] = int(ch)
         cfg.kernel_size = kernel_size
-        cfg.horizon = horizon
+        cfg.horizon = self.padded_horizon
         cfg.n_timesteps = n_timesteps
         cfg.predict_epsilon = int(predict_epsilon)
         cfg.clip_denoised = int(clip_denoised)
@@ -221,9 +242,12 @@ class HipEngine:
         _check(self.lib, self.lib.dad_model_create(C.byref(cfg), C.byref(handle)))
         self._h = handle
         _check(self.lib, self.lib.dad_model_set_precision(self._h, PRECISIONS[precision]))
-        if self.padded:
+        self.widths_padded = padded != self.real_channels
+        if self.widths_padded:
             real = (C.c_int32 * len(self.real_channels))(*self.real_channels)
             _check(self.lib, self.lib.dad_model_set_group_channels(self._h, real, len(self.real_channels)))
+        if self.rows_padded:
+            _check(self.lib, self.lib.dad_model_set_horizon(self._h, horizon))
         self.training = bool(training)
         if self.training:
             _check(self.lib, self.lib.dad_model_set_training(self._h, 1))
@@ -245,7 +269,7 @@ class HipEngine:
              schedule: Mapping[str, torch.Tensor]) -> None:
         """Upload every denoiser tensor (reference state_dict keys without ``model.``) and
         the five schedule buffers, then build tables and the launch plan."""
-        if self.padded:
+        if self.widths_padded:
             from .utils import padding
             mults = [c // self.real_dim for c in self.real_channels]
             unet_state, _, _ = padding.pad_unet_state(unet_state, self.transition_dim, self.real_dim, mults)
@@ -265,7 +289,7 @@ class HipEngine:
             bufs.append(b)
         _check(self.lib, self.lib.dad_model_load_schedule(self._h, *[b.data_ptr() for b in bufs]))
         emb = sinusoid_table(self.n_timesteps, self.real_dim)
-        if self.padded:                    # the real columns in front, as time_mlp.1.weight is padded
+        if self.widths_padded:             # the real columns in front, as time_mlp.1.weight is padded
             wide = torch.zeros(self.n_timesteps, int(self.cfg.dim))
             wide[:, :self.real_dim] = emb
             emb = wide.contiguous()

@@ -102,6 +102,9 @@ struct ConvParams {
     int32_t cin_pad;     // (cin0+cin1) rounded up to KC
     int32_t M;           // GEMM columns (2*C_out for the transposed conv)
     int32_t cpg;         // channels per GroupNorm group (M/8) when gamma != nullptr
+    int32_t lreal;       // > 0: only the first lreal GEMM rows of every sample exist (dad_model_set_horizon): the rest are
+                         // padding — left out of the statistics and stored as zeros (the next conv's halo); 0: all
+    int32_t src_len;     // > 0: src0 is the external trajectory with src_len rows per sample (its real horizon)
     int32_t cpg_real;    // > 0: only the first cpg_real channels of every group exist (dad_model_set_group_channels:
                          // the rest are zero padding and do not count in the statistics); 0: all of them
     int32_t B;           // batch rows in this call
@@ -218,8 +221,11 @@ __device__ __forceinline__ void store_f4_sc1(float* p, const float4 v) {
 // roll like the staged items: those of unit u are consumed by the unit's MFMAs and the registers
 // immediately receive the same unit of the next chunk.  Weights are packed in 16-channel granules
 // for both arithmetics: [granule][tap][M][16 floats] (split-f16: 16 hi halves | 16 lo halves).
+// PADDED: the zero-padded forms (dad_model_set_horizon / dad_model_set_group_channels) as their own instantiations —
+// as runtime branches of the one kernel they cost the BASELINE configurations 0.4-0.8 % (A/B of two builds on one
+// box): the unpadded kernels are instruction for instruction what they were.
 template <int BM, int BN, int SK, int KC, int TAPS, int STRIDE, bool RAGGED, bool X3 = false, bool BDIR = false,
-          bool RES = false>
+          bool RES = false, bool PADDED = false>
 __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32(const ConvParams p) {
     constexpr int TMW = BM / 32;                 // wave tiles along M
     constexpr int TNW = BN / 32;                 // wave tiles along N
@@ -352,6 +358,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
         const int l = row - (s << p.lshift_in);
         const bool ok = e < xrows_real * KQ && s < nvalid;
         x_grow[i] = ok ? s0 * Lin + row : -1;
+        if constexpr (PADDED)
+            if (p.src_len > 0)                              // external trajectory of a zero-padded horizon
+                x_grow[i] = (ok && l < p.src_len) ? (s0 + s) * p.src_len + l : -1;
         x_q4[i] = q * 4;
         // split-f16 rows: per 16-channel unit [8 floats of hi halves | 8 floats of lo halves]
         const int qoff = X3 ? (q >> 2) * 16 + (q & 3) * 2 : q * 4;
@@ -822,8 +831,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
     }
 
     if (has_gn) {
-        const int creal = p.cpg_real > 0 ? p.cpg_real : cpg;        // channels of a group that exist
-        const float inv_cnt = 1.0f / (float)(Lout * creal);          // (= cnt4 * 4 without padding)
+        const int creal = (PADDED && p.cpg_real > 0) ? p.cpg_real : cpg;      // channels of a group that exist
+        const int lr = (PADDED && p.lreal > 0) ? p.lreal : Lout;               // positions of a sample that exist
+        const float inv_cnt = PADDED ? 1.0f / (float)(lr * creal) : 1.0f / (float)(cnt4 * 4);
         const int width = lpp < 64 ? lpp : 64;
         const int wpp = lpp >> 6;                      // waves per pair when a pair spans waves
         auto pair_sum = [&](float v, int slot) -> float {
@@ -844,16 +854,25 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
             return v;
         };
         float sum = 0.0f;
+        if constexpr (PADDED) {
+            // padded positions hold conv + bias of the edge rows (not zero): left out of both passes; padded channels
+            // hold exactly zero: nothing for the sum, masked in the variance
 #pragma unroll
-        for (int k = 0; k < F4PL; ++k) sum += (y[k][0] + y[k][1]) + (y[k][2] + y[k][3]);
+            for (int k = 0; k < F4PL; ++k)
+                if ((erow[k] & (Lout - 1)) < lr) sum += (y[k][0] + y[k][1]) + (y[k][2] + y[k][3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < F4PL; ++k) sum += (y[k][0] + y[k][1]) + (y[k][2] + y[k][3]);
+        }
         const float mean = pair_sum(sum, 0) * inv_cnt;
         float sq = 0.0f;
-        if (p.cpg_real > 0) {                          // (block-uniform) padded groups: the zero channels hold
-#pragma unroll                                          // conv + bias = 0 exactly — nothing for the sum, masked here
+        if constexpr (PADDED) {
+#pragma unroll
             for (int k = 0; k < F4PL; ++k) {
                 const int cl = ecol[k] & (cpg - 1);    // channel of the float4 inside its group
+                const bool row_on = (erow[k] & (Lout - 1)) < lr;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { const float d = cl + c < creal ? y[k][c] - mean : 0.0f; sq += d * d; }
+                for (int c = 0; c < 4; ++c) { const float d = (row_on && cl + c < creal) ? y[k][c] - mean : 0.0f; sq += d * d; }
             }
         } else {
 #pragma unroll
@@ -878,6 +897,12 @@ __global__ __launch_bounds__(64 * (BM / 32) * (BN / 32) * SK) void conv_gemm_f32
 #pragma unroll
     for (int k = 0; k < F4PL; ++k) {
         if (eoff[k] < 0) continue;
+        if constexpr (PADDED) {                        // zero-padded horizon: the padding stays zero
+            if (p.lreal > 0 && (erow[k] & (Lout - 1)) >= p.lreal) {
+                store_f4_sc1(p.dst + eoff[k], make_float4(0.f, 0.f, 0.f, 0.f));
+                continue;
+            }
+        }
         // absent operands were loaded from the bias row: cancelled with a select (v_cndmask), not a
         // multiply by 0 — 0 * Inf would turn a non-finite word of an unrelated tensor into NaN here
         const float4 t4 = has_temb ? temb4[k] : make_float4(0.f, 0.f, 0.f, 0.f);

@@ -146,22 +146,38 @@ void free_device(dad_model* m) {
 // ---------------------------------------------------------------------- kernel registry
 // Every conv-GEMM instantiation the planner can ask for, keyed by what plan_launch decides.
 using KernFn = void (*)(const ConvParams);
-using KernKey = std::tuple<int, int, int, bool, bool, bool, bool>;   // cfg, taps, stride, x3, bdir, ragged, res
+using KernKey = std::tuple<int, int, int, bool, bool, bool, bool, bool>;   // cfg, taps, stride, x3, bdir, ragged, res, padded
 using KernTable = std::map<KernKey, KernFn>;
 
 template <int CFG> struct Tile {
     static constexpr int BM = kTiles[CFG].BM, BN = kTiles[CFG].BN, SK = kTiles[CFG].SK, KC = kTiles[CFG].KC;
 };
 
-template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR, bool RES>
+template <int CFG, int TAPS, int STRIDE, bool X3, bool BDIR, bool RES, bool PADDED = false>
 void reg_kernel(KernTable& t) {
     using T = Tile<CFG>;
     constexpr int KC = eff_kc(T::KC, T::BM, TAPS, T::SK, X3, BDIR, T::BN);
-    t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, false, RES)] =
-        dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR, RES>;
+    t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, false, RES, PADDED)] =
+        dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, false, X3, BDIR, RES, PADDED>;
     if constexpr (!BDIR && STRIDE == 1 && (TAPS & 1) == 1)             // general staging path
-        t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, true, RES)] =
-            dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, true, X3, BDIR, RES>;
+        t[KernKey(CFG, TAPS, STRIDE, X3, BDIR, true, RES, PADDED)] =
+            dad::conv_gemm_f32<T::BM, T::BN, T::SK, KC, TAPS, STRIDE, true, X3, BDIR, RES, PADDED>;
+}
+// Zero-padded nets (dad_model_set_horizon / dad_model_set_group_channels): fp32, no ride, on the tiles the heuristic
+// picks (kPaddedTiles of host_plan.hpp)
+template <int CFG>
+void reg_tile_padded(KernTable& t) {
+    reg_kernel<CFG, 5, 1, false, false, false, true>(t);
+    reg_kernel<CFG, 3, 1, false, false, false, true>(t);
+    reg_kernel<CFG, 7, 1, false, false, false, true>(t);
+    reg_kernel<CFG, 3, 2, false, false, false, true>(t);
+    reg_kernel<CFG, 2, 1, false, false, false, true>(t);
+    reg_kernel<CFG, 1, 1, false, false, false, true>(t);
+    if constexpr (Tile<CFG>::KC < 16) {
+        reg_kernel<CFG, 5, 1, false, true, false, true>(t);
+        reg_kernel<CFG, 3, 1, false, true, false, true>(t);
+        reg_kernel<CFG, 7, 1, false, true, false, true>(t);
+    }
 }
 template <int CFG>
 void reg_tile(KernTable& t) {
@@ -196,6 +212,8 @@ const KernTable& kernel_table() {
         reg_tile<0>(t); reg_tile<1>(t); reg_tile<2>(t); reg_tile<3>(t);
         reg_tile<4>(t); reg_tile<5>(t); reg_tile<6>(t); reg_tile<7>(t);
         reg_tile<8>(t); reg_tile<9>(t);
+        reg_tile_padded<0>(t); reg_tile_padded<1>(t); reg_tile_padded<2>(t); reg_tile_padded<3>(t);
+        reg_tile_padded<4>(t); reg_tile_padded<8>(t); reg_tile_padded<9>(t);
         return t;
     }();
     return table;
@@ -361,6 +379,7 @@ int launch_conv(dad_model* m, const ConvOp& op, int batch, const ConvIO& io, hip
     p.pre = io.pre; p.stats = io.stats;
     p.cin0 = op.cin0; p.cin1 = op.cin1; p.cin_pad = op.cin_pad;
     p.M = op.M; p.cpg = op.norm.empty() ? 0 : op.cout / 8; p.cpg_real = op.gn_real;
+    p.lreal = op.lreal; p.src_len = op.src_len;
     p.B = batch; p.Lin = op.Lin; p.Lout = op.Lout; p.lshift = ilog2(op.Lout);
     p.lshift_in = ilog2(op.Lin);
     p.interleave = op.kind == CONV_UP;
@@ -387,7 +406,7 @@ int launch_conv(dad_model* m, const ConvOp& op, int batch, const ConvIO& io, hip
                    ? g_stamps + (size_t)(&op - &m->plan.convs[0]) * 4096 * 8 : nullptr;
 #endif
     const auto& table = kernel_table();
-    const auto it = table.find(KernKey(g.cfg, op.taps, op.stride, op.x3, op.bdir, g.ragged, g.fused));
+    const auto it = table.find(KernKey(g.cfg, op.taps, op.stride, op.x3, op.bdir, g.ragged, g.fused, g.padded));
     if (it == table.end())
         return fail(DAD_E_INVALID, "no kernel for %s (tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d)",
                     op.name.c_str(), g.cfg, op.taps, op.stride, (int)op.x3, (int)op.bdir, (int)g.ragged, (int)g.fused);
@@ -406,6 +425,9 @@ int ensure_tables(dad_model* m, hipStream_t st) {
     if (rc == DAD_OK) m->tables_stale = false;
     return rc;
 }
+
+// rows per sample of the external tensors (x, noise, guide, means): the horizon before zero-padding
+inline int traj_horizon(const dad_model* m) { return m->real_horizon > 0 ? m->real_horizon : m->cfg.horizon; }
 
 int check_ready(const dad_model* m, int batch, int t, size_t ws_bytes) {
     if (!m) return fail(DAD_E_INVALID, "null model");
@@ -570,7 +592,7 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
     const Plan& plan = train ? m->tplan : m->plan;
     p.act = ws + plan.bufs[plan.final_act].offset * (long)batch;
     p.w = m->d_final_w; p.bias = m->d_final_b;
-    p.dim = c.dim; p.td = c.transition_dim; p.B = batch; p.H = c.horizon;
+    p.dim = c.dim; p.td = c.transition_dim; p.B = batch; p.H = traj_horizon(m); p.Hact = c.horizon;
     p.predict_epsilon = c.predict_epsilon; p.clip_denoised = c.clip_denoised;
     if (eps_only) {
         p.x = const_cast<float*>(x_ro);
@@ -588,7 +610,7 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         p.sigma = t == 0 ? 0.0f : expf(0.5f * lv);
         p.guide_scale = a->guide_weight * expf(lv);
         p.seed = a->seed;
-        p.elem_offset = a->row_offset * (uint64_t)c.horizon * (uint64_t)c.transition_dim;
+        p.elem_offset = a->row_offset * (uint64_t)traj_horizon(m) * (uint64_t)c.transition_dim;
         p.draw = a->draw;
         p.seed_dev = seed_from_device ? (const unsigned long long*)m->d_rng : nullptr;
     }
@@ -609,7 +631,7 @@ int run_final(dad_model* m, float* x, const float* x_ro, int t, int batch, const
         HIP_TRY(hipGetLastError());
         return DAD_OK;
     }
-    const long N = (long)batch * c.horizon;
+    const long N = (long)batch * traj_horizon(m);
     // columns of the transition are spread over gridDim.y when the row tiles alone leave CUs idle
     // (a block stages only the weight rows of its own columns), and further until a block fits LDS
     const long row_tiles = (N + dad::FINAL_COLS - 1) / dad::FINAL_COLS;
@@ -797,6 +819,20 @@ int dad_model_set_precision(dad_model* m, int32_t precision) {
     if (precision != m->precision) m->finalized = false;       // weights must be re-packed
     m->precision = precision;
     decide_kernel_families(m);
+    return DAD_OK;
+}
+
+int dad_model_set_horizon(dad_model* m, int32_t real_horizon) {
+    if (!m) return fail(DAD_E_INVALID, "null model");
+    const int padded = m->cfg.horizon, down = 1 << (m->cfg.n_levels - 1);
+    if (real_horizon < down || real_horizon > padded || real_horizon % down != 0)
+        return fail(DAD_E_INVALID, "horizon %d: need a multiple of 2^(levels-1) = %d (every level halves the length) of at most the "
+                    "padded horizon %d", real_horizon, down, padded);
+    m->real_horizon = real_horizon == padded ? 0 : real_horizon;
+    const int rc = build_plan(m);                 // the same plan; every conv now knows how many of its rows exist
+    if (rc != DAD_OK) return rc;
+    m->finalized = false;
+    if (m->training) if (const char* why = training_refusal(*m)) return fail(DAD_E_INVALID, "training: %s", why);
     return DAD_OK;
 }
 
@@ -1009,7 +1045,7 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
     if (proj && !proj_alphas_host) return fail(DAD_E_INVALID, "projection needs per-step alphas");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = ensure_tables(m, st)) != DAD_OK) return rc;      // (before any capture: the replayed loop reads the tables)
-    const long step_elems = (long)batch * m->cfg.horizon * m->cfg.transition_dim;
+    const long step_elems = (long)batch * traj_horizon(m) * m->cfg.transition_dim;
 
     const bool seed_dev = use_graph && !m->profile && noise_stack == nullptr;
     const CcPlan cc = cc_plan(*m, batch);
@@ -1026,7 +1062,7 @@ int dad_sample_loop(dad_model* m, float* x, int32_t n_steps, int32_t batch,
             if ((r = run_final(m, x, nullptr, t, batch, &a, 0, nullptr, (float*)workspace, st,
                                seed_dev, ccp)) != DAD_OK)
                 return r;
-            if (proj && (r = run_project(proj, proj_alphas_host[t], x, batch, m->cfg.horizon, st)) != DAD_OK)
+            if (proj && (r = run_project(proj, proj_alphas_host[t], x, batch, traj_horizon(m), st)) != DAD_OK)
                 return r;
         }
         return DAD_OK;
@@ -1592,12 +1628,12 @@ int dad_debug_kernel_table_consistent(void) {
     for (int cfg = 0; cfg < kNumTiles; ++cfg)
         for (int taps = 1; taps <= 7; ++taps)
             for (int stride = 1; stride <= 2; ++stride)
-                for (int f = 0; f < 16; ++f) {
-                    const bool x3 = f & 1, bdir = f & 2, ragged = f & 4, res = f & 8;
-                    const bool have = t.count(KernKey(cfg, taps, stride, x3, bdir, ragged, res)) != 0;
-                    if (have != kernel_registered(cfg, taps, stride, x3, bdir, ragged, res)) {
-                        fail(DAD_E_INVALID, "kernel table mismatch at tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d (registry %d)",
-                             cfg, taps, stride, (int)x3, (int)bdir, (int)ragged, (int)res, (int)have);
+                for (int f = 0; f < 32; ++f) {
+                    const bool x3 = f & 1, bdir = f & 2, ragged = f & 4, res = f & 8, padded = f & 16;
+                    const bool have = t.count(KernKey(cfg, taps, stride, x3, bdir, ragged, res, padded)) != 0;
+                    if (have != kernel_registered(cfg, taps, stride, x3, bdir, ragged, res, padded)) {
+                        fail(DAD_E_INVALID, "kernel table mismatch at tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d padded=%d (registry %d)",
+                             cfg, taps, stride, (int)x3, (int)bdir, (int)ragged, (int)res, (int)padded, (int)have);
                         return 0;
                     }
                     hits += have;

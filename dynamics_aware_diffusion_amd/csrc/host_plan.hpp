@@ -73,7 +73,11 @@ struct ConvOp {
     // GroupNorm'd conv — its pre-normalisation output (conv + bias) and the (mean, rstd) of every
     // (sample, group) pair, [8][2] floats per sample
     int pre = -1, stats = -1;
+    bool net_padded = false; // the model has zero-padded rows or channels: every launch takes the PADDED kernels
     int gn_real = 0;         // > 0: channels per GroupNorm group that exist (the rest of the group is zero padding)
+    int lreal = 0;           // > 0: GEMM output rows per sample that exist (dad_model_set_horizon: the rest are zero
+                             //      padding: masked in the GroupNorm statistics, stored as zeros); 0: all of them
+    int src_len = 0;         // > 0: rows per sample of the EXTERNAL src0 (the trajectory keeps its real horizon)
     // device tensors (owned by the model)
     float* d_w = nullptr;
     float* d_bias = nullptr;
@@ -82,6 +86,7 @@ struct ConvOp {
     float* d_rbias = nullptr;
     double flops_per_sample = 0;
     int wtaps() const { return taps + (ride ? 1 : 0); }      // tap slots of the packed image
+    bool padded() const { return gn_real > 0 || lreal > 0 || src_len > 0; }   // runs the PADDED kernel instantiations
 };
 
 struct Buf {
@@ -153,6 +158,7 @@ struct HostModel {
     int chain_min_batch = 64;                                  //   from this batch on (one block per sample: below, the
                                                                //   chip is mostly idle and the batch kernels' split-K wins)
     int real_channels[DAD_MAX_LEVELS] = {0};                   // dad_model_set_group_channels: widths before padding (0: as cfg)
+    int real_horizon = 0;                                      // dad_model_set_horizon: horizon before padding (0: as cfg)
     int wgrad_blocks = 256;                                    // blocks a weight-gradient launch aims for (tiles x batch splits)
     bool ccw_prefer16 = true;                                  //   two 16-row tiles instead of an LDS-short 32-row one
                                                                //   (measured crossover: batch 16 at H = 32)
@@ -238,16 +244,20 @@ inline void expect(HostModel* m, const std::string& key, std::vector<int64_t> sh
 //         granules, and for the strided / transposed convs (no general staging path) whole
 //         64-channel chunks
 inline void decide_kernel_families(HostModel* m) {
+    // a zero-padded net (rows or channels) runs the PADDED instantiations everywhere: fp32, no ride
+    bool padded_net = m->real_horizon > 0 && m->real_horizon != m->cfg.horizon;
+    for (int i = 0; i < m->cfg.n_levels; ++i) padded_net = padded_net || (m->real_channels[i] > 0 && m->real_channels[i] != m->cfg.channels[i]);
     for (Plan* plan : {&m->plan, &m->tplan})
     for (ConvOp& op : plan->convs) {
         const int cin_all = op.cin0 + op.cin1;
         op.bdir = op.kc == 8 && op.kind == CONV_K5 &&
                   (op.cin0 % 32) == 0 && (cin_all % 32) == 0 && op.cin_pad == cin_all;
-        op.ride = !op.rname.empty() && !op.bdir && m->precision == DAD_PREC_FP32;
-        op.x3 = (op.bdir && m->precision == DAD_PREC_F16X3) ||
+        op.ride = !op.rname.empty() && !op.bdir && m->precision == DAD_PREC_FP32 && !padded_net;
+        op.x3 = !padded_net && ((op.bdir && m->precision == DAD_PREC_F16X3) ||
                 (m->precision == DAD_PREC_F16X3 && op.kc == 16 &&
                  ((op.kind == CONV_K5 && op.taps == 5) || op.kind == CONV_1X1 ||
-                  ((op.kind == CONV_DOWN || op.kind == CONV_UP) && (op.cin0 & 63) == 0 && (cin_all & 63) == 0)));
+                  ((op.kind == CONV_DOWN || op.kind == CONV_UP) && (op.cin0 & 63) == 0 && (cin_all & 63) == 0))));
+        op.net_padded = padded_net;
     }
 }
 
@@ -262,6 +272,8 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
     int temb_off = 0;
 
     int level_now = 0;               // level whose width the convs being emitted produce
+    const bool rows_padded = m->real_horizon > 0 && m->real_horizon != c.horizon;
+    int Lr_now = rows_padded ? m->real_horizon : c.horizon;      // real positions at the level being emitted
     auto conv = [&](const std::string& name, const std::string& norm, ConvKind kind, int src0,
                     int src1, int cin0, int cin1, int cout, int Lin, int dst, int res,
                     int toff) {
@@ -269,6 +281,13 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
         op.name = name; op.norm = norm; op.kind = kind;
         const int real = m->real_channels[level_now];
         if (!norm.empty() && real > 0 && real != cout) op.gn_real = real / 8;
+        if (rows_padded) {
+            // real rows per sample of the GEMM's output (the transposed conv's GEMM rows are its INPUT positions)
+            const int lr_out = kind == CONV_DOWN ? Lr_now / 2 : Lr_now;
+            const int lp_out = kind == CONV_DOWN ? Lin / 2 : Lin;
+            if (lr_out != lp_out) op.lreal = lr_out;
+            if (src0 == -2) op.src_len = Lr_now;
+        }
         op.cin0 = cin0; op.cin1 = cin1;
         op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
         const int padto = op.kc == 8 ? 8 : (kind == CONV_1X1 ? 128 : 64);   // deepest K chunk of its kernels
@@ -366,6 +385,7 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
             const int d = A.get((long)co * (L / 2));
             conv(b + ".2.conv", "", CONV_DOWN, h2, -1, co, 0, co, L, d, -1, -1);
             L /= 2;
+            Lr_now /= 2;
             x = d;
             if (i == 0) A.put(h2);   // level-0 skip is pushed but never popped (F8)
         } else {
@@ -396,9 +416,13 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
         conv(b + ".2.conv", "", CONV_UP, u2, -1, co, 0, co, L, up, -1, -1);
         A.put(u2);
         L *= 2;
+        Lr_now *= 2;
         x = up;
         cx = co;
     }
+    if (rows_padded)
+        for (const ConvOp& op : P.convs)
+            if (op.res == -2) plan_error = "transition_dim == dim (the first block's residual is the trajectory itself) with a zero-padded horizon";
     if (plan_error != nullptr) return fail(DAD_E_INVALID, "%s", plan_error);
     if (cx != c.dim)
         return fail(DAD_E_INVALID, "final_conv expects %d channels but the decoder ends with %d "
@@ -497,6 +521,7 @@ inline const char* training_refusal(const HostModel& m) {
     if (m.precision != DAD_PREC_FP32) return "the backward pass exists for the fp32 arithmetic only";
     for (const ConvOp& op : m.tplan.convs)
         if (op.gn_real > 0) return "widths that are not a multiple of 32 with a power-of-two C/8 run on zero-padded GroupNorm groups: inference only";
+    if (m.real_horizon > 0 && m.real_horizon != m.cfg.horizon) return "a horizon that is not a power of two runs zero-padded: inference only";
     for (const ConvOp& op : m.tplan.convs)
         if (op.cat0 >= 0) return "identity residual over a channel concat (shrinking dim_mults) has no backward kernel";
     return nullptr;
@@ -698,8 +723,10 @@ inline int pack_bwd_final(HostModel* m, std::vector<float>& out) {
 // (BN % L == 0), BM divides the columns (each phase half for the transposed conv), the K chunk
 // matches the packed weights.  Preference: enough blocks to cover the 256 CUs; when tiles are
 // scarce, trade tile size for split-K depth.
+constexpr bool kPaddedTiles[kNumTiles] = {true, true, true, true, true, false, false, false, true, true};
 inline bool tile_valid(const ConvOp& op, int cfg) {
     const TileCfg& t = kTiles[cfg];
+    if (op.net_padded && !kPaddedTiles[cfg]) return false;      // (PADDED kernels exist for the heuristic's tiles)
     const int Mrows = op.kind == CONV_UP ? op.M / 2 : op.M;
     const int cpg = op.norm.empty() ? 1 : op.cout / 8;
     if ((t.KC == 8) != (op.kc == 8)) return false;
@@ -833,6 +860,7 @@ struct LaunchGeom {
     unsigned gx = 1, gy = 1, gz = 1;
     int xcd_gn = 0, xcd_mts = 0, xcd_ntn = 0;
     bool fused = false;      // the residual conv rides in this launch
+    bool padded = false;     // PADDED instantiation (zero-padded rows / channels)
     SplitPlan split{1, 0, 0};
     uint64_t xswz = 0;
 };
@@ -853,8 +881,9 @@ inline bool fused_at(const HostModel& m, const ConvOp& op, int batch) {
 // Which conv-GEMM instantiations exist (the registry of dad_lib.hip, reg_tile, restated on the host so that the
 // planner — and the sanitizer harness, which has no device code — refuses a launch no kernel was compiled for;
 // dad_debug_kernel_table_consistent() compares the two).
-inline bool kernel_registered(int cfg, int taps, int stride, bool x3, bool bdir, bool ragged, bool res) {
+inline bool kernel_registered(int cfg, int taps, int stride, bool x3, bool bdir, bool ragged, bool res, bool padded = false) {
     if (cfg < 0 || cfg >= kNumTiles) return false;
+    if (padded && (!kPaddedTiles[cfg] || x3 || res || (stride == 2 && taps != 3))) return false;
     const bool kc16 = kTiles[cfg].KC >= 16;
     const bool k357 = taps == 3 || taps == 5 || taps == 7;
     if (ragged && !(stride == 1 && (k357 || taps == 1) && !bdir)) return false;
@@ -893,9 +922,10 @@ inline int plan_launch(HostModel& m, const ConvOp& op, int batch, LaunchGeom& g)
     if (op.cin_pad % g.kc != 0 && !g.ragged)
         return fail(DAD_E_INVALID, "%s: padded channel count %d is not a multiple of the K chunk %d",
                     op.name.c_str(), op.cin_pad, g.kc);
-    if (!kernel_registered(g.cfg, op.taps, op.stride, op.x3, op.bdir, g.ragged, g.fused))
-        return fail(DAD_E_INVALID, "no kernel for %s (tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d)",
-                    op.name.c_str(), g.cfg, op.taps, op.stride, (int)op.x3, (int)op.bdir, (int)g.ragged, (int)g.fused);
+    g.padded = op.net_padded;
+    if (!kernel_registered(g.cfg, op.taps, op.stride, op.x3, op.bdir, g.ragged, g.fused, g.padded))
+        return fail(DAD_E_INVALID, "no kernel for %s (tile %d taps=%d stride=%d x3=%d bdir=%d ragged=%d res=%d padded=%d)",
+                    op.name.c_str(), g.cfg, op.taps, op.stride, (int)op.x3, (int)op.bdir, (int)g.ragged, (int)g.fused, (int)g.padded);
     g.threads = 64 * (t.BM / 32) * (t.BN / 32) * t.SK;
     g.lds_bytes = dad::conv_lds_floats(t.BM, t.BN, g.kc, op.taps, op.Lin, op.Lout, t.SK, op.bdir,
                                        op.taps + (g.fused ? 1 : 0)) * sizeof(float);
@@ -985,6 +1015,7 @@ inline CcPlan cc_plan(const HostModel& m, int batch) {
         return refuse(P, "horizon > 32 and more than 256 rows");
     for (const ConvOp& op : convs)
         if (op.gn_real > 0) return refuse(P, "zero-padded GroupNorm groups (dad_model_set_group_channels): batch kernels only");
+    if (m.real_horizon > 0 && m.real_horizon != c.horizon) return refuse(P, "zero-padded horizon (dad_model_set_horizon): batch kernels only");
     for (const ConvOp& op : convs)      // weight images in 16-channel granules only
         if ((op.kc != 16 && !op.bdir) || op.cat0 >= 0 || op.x3 || (!op.rname.empty() && !op.ride)) return refuse(P, "a weight image not in 16-channel granules, or an identity residual over a concat");
     P.ops.resize(convs.size());
@@ -1150,7 +1181,8 @@ inline ChainPlan chain_plan(const HostModel& m) {
     ChainPlan P;
     const dad_cfg& c = m.cfg;
     const std::vector<ConvOp>& v = m.plan.convs;
-    if (m.precision != DAD_PREC_FP32 || c.kernel_size != 5 || c.horizon != 32 || c.n_levels < 2) return P;
+    if (m.precision != DAD_PREC_FP32 || c.kernel_size != 5 || c.horizon != 32 || c.n_levels < 2 ||
+        (m.real_horizon > 0 && m.real_horizon != c.horizon)) return P;
     const int C = c.channels[0];
     if ((C != 32 && C != 64 && C != 128) || c.transition_dim > 16 || c.transition_dim == C || v.size() < 6) return P;
     // the plan order of build_plan: conv0 (+ride), its stand-alone 1x1 form, conv1, conv0', conv1', down

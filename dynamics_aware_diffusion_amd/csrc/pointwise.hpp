@@ -80,6 +80,7 @@ struct FinalParams {
     float* mean_out;         // optional
     float* eps_out;          // optional
     int32_t dim, td, B, H;
+    int32_t Hact;            // rows per sample of `act` (the zero-padded horizon; == H without padding)
     int32_t cond_per_row;
     int32_t predict_epsilon, clip_denoised;
     int32_t x_out_disabled;  // 1: only eps_out / mean_out are produced
@@ -146,7 +147,11 @@ __global__ __launch_bounds__(256) void final_posterior_kernel(const FinalParams 
     for (int e = threadIdx.x; e < FINAL_COLS * dq; e += blockDim.x) {
         const int row = e / dq, q = e - row * dq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 + row < N) v = *reinterpret_cast<const float4*>(p.act + (n0 + row) * dim + q * 4);
+        if (n0 + row < N) {
+            long ar = n0 + row;                      // row of the activation buffer: sample * Hact + position
+            if (p.Hact != p.H) { const long sb = ar / p.H; ar = sb * p.Hact + (ar - sb * p.H); }
+            v = *reinterpret_cast<const float4*>(p.act + ar * dim + q * 4);
+        }
         *reinterpret_cast<float4*>(tile + row * rs + q * 4) = v;
     }
     // blockIdx.y owns the output columns j with (j / JG) % gridDim.y == blockIdx.y: wide transitions

@@ -112,6 +112,15 @@ int dad_model_set_precision(dad_model* m, int32_t precision);
  * between dad_model_create and dad_model_finalize.  Such models run the batch kernels at every batch size and are
  * refused by dad_model_set_training. */
 int dad_model_set_group_channels(dad_model* m, const int32_t* real_channels, int32_t n_levels);
+
+/* Horizons the reference accepts and the tiles do not: its U-Net takes any length every level can halve
+ * (temporal_unet.py:35-54: H % 2^(levels-1) == 0 — 24, 48, 96, 100 ...), the conv-GEMM tiles whole power-of-two
+ * samples.  Give the next power of two in dad_cfg.horizon and the real horizon here: every activation keeps the padded
+ * layout with ZERO rows behind the real ones (exactly the zero padding a conv sees at the end of a sample), the
+ * GroupNorm statistics count the real rows only, and the external tensors (x, noise, guide gradient, outputs) keep
+ * the real shape (B, real_horizon, transition_dim).  Call between dad_model_create and dad_model_finalize.  Such models
+ * run the batch kernels at every batch size and are refused by dad_model_set_training. */
+int dad_model_set_horizon(dad_model* m, int32_t real_horizon);
 /* Checks every tensor is present, builds the per-timestep time-embedding tables
  * (SinusoidalPosEmb + time_mlp + every block's Mish->Linear, temporal_unet.py:19-32,
  * 97-100,155-160 — batch-invariant during sampling) and the launch plan. */

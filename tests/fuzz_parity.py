@@ -39,9 +39,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     nlev = rng.choice([1, 2, 3, 4])
     mults = tuple([1] + [rng.choice([1, 2, 4, 8] + ([3] if knobs and not grads else [])) for _ in range(nlev - 1)])
     if grads: mults = tuple(sorted(mults))
-    H = rng.choice([8, 16, 32, 64] + ([128] if knobs else []))
+    H = rng.choice([8, 16, 32, 64] + ([128, 12, 24, 40, 48, 96, 100] if knobs else []))
     ks = rng.choice([3, 5, 5, 7]) if knobs else 5
-    if H >> (nlev - 1) < 4 or max(mults) * dim > 2048:
+    if ((H >> (nlev - 1) < 4 or H & (H - 1)) and not knobs) or H % (1 << (nlev - 1)) or max(mults) * dim > 2048:
         continue
     if wide and (max(mults) * dim < 1024 or H > 32):
         continue
@@ -85,7 +85,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
         gtxt = ""
         gerr = 0.0
         shrinking = any(b < a for a, b in zip(mults, mults[1:]))
-        if knobs and (grads or it % 3 == 0) and prec == "fp32" and not eng.padded and not shrinking and td != dim:
+        if knobs and (grads or it % 3 == 0) and prec == "fp32" and not eng.padded and not (H & (H - 1)) and H >> (nlev - 1) >= 4 and not shrinking and td != dim:
             Bg = min(B, 6)
             x0 = torch.from_numpy(np.clip(synth.normal_like(400 + it, "fuzz.x0", (Bg, H, td)) * 0.5, -1, 1).astype(np.float32))
             tt = torch.from_numpy(np.array([(3 * i + 1) % 20 for i in range(Bg)], dtype=np.int64))

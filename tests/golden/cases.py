@@ -116,6 +116,23 @@ FORWARD_CASES = [
     ("fwd_tiny_d24", "tiny_d24", 6, 15),
 ]
 
+# Horizons every level can halve but that are not a power of two (temporal_unet.py:35-54 accepts any such length;
+# the engine runs them zero-padded to the next power of two).  (case, net, horizon, B, t): a forward + its fp64 run,
+# and a conditioned T-step loop of the net's own schedule length with injected noise.
+HORIZON_CASES = [
+    ("hz_tiny_H24", "tiny", 24, 3, 5),
+    ("hz_tiny_H12", "tiny", 12, 5, 17),
+    ("hz_tiny4_H40", "tiny4", 40, 2, 9),
+]
+
+
+def horizon_inputs(case: str, net: str, horizon: int, B: int, T: int):
+    _, _, td, _, _ = net_dims(net)
+    x = synth.normal_like(27, case + ".x", (B, horizon, td))
+    noise = synth.normal_like(27, case + ".noise", (T + 1, B, horizon, td))
+    return x, noise
+
+
 # (case, net, T_train, n_sample_steps, B, conditioned, schedule)
 LOOP_CASES = [
     ("loop_tiny_T20_B1", "tiny", 20, 20, 1, False, "cosine"),

@@ -230,6 +230,36 @@ def gen_loops():
         save(case, **out)
 
 
+def gen_horizons():
+    """Non-power-of-two horizons: the reference's own modules at H = 24 / 12 / 40 (forward, fp64 forward, a
+    conditioned sampling loop with injected noise)."""
+    for case, net, Hz, B, t in cases.HORIZON_CASES:
+        if CASE_FILTER and case not in CASE_FILTER:
+            continue
+        print(f"  horizon {case} ...")
+        od, ad, td, dim, mults = cases.net_dims(net)
+        T = cases.NETS[net][4]
+        unet = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults)).eval()
+        load_into(unet, cases.net_weights(net))
+        diff = GaussianDiffusion(unet, Hz, od, ad, n_timesteps=T, beta_schedule="cosine").eval()
+        x, noise = cases.horizon_inputs(case, net, Hz, B, T)
+        tt = torch.full((B,), t, dtype=torch.long)
+        with torch.no_grad():
+            eps = unet(torch.from_numpy(x), tt)
+            u64 = ref_unet.TemporalUnet(td, dim=dim, dim_mults=tuple(mults)).eval()
+            load_into(u64, cases.net_weights(net))
+            u64 = u64.double()
+            pos = u64.time_mlp[0]
+            orig = pos.forward
+            pos.forward = lambda tt_, orig=orig: orig(tt_).double()
+            eps64 = u64(torch.from_numpy(x).double(), tt)
+        pol = ref_pol.GuidedPolicy(diff, normalizer=None)
+        cond = {0: torch.from_numpy(cases.loop_condition(case, net))}
+        with injected_noise(noise):
+            xf = pol.sample_loop(batch_size=B, conditions=cond)
+        save(case, eps=eps.numpy(), eps_fp64=eps64.numpy(), x_final=xf.numpy())
+
+
 def gen_long_loops():
     """BASELINE configs 4 / 5 at T = 1000 (two plans): the reference's own loops, unrolled by the
     harness exactly as diffusion.py:241-249 / policies.py:134-147 do so that x can be recorded
@@ -527,7 +557,7 @@ CASE_FILTER: set = set()          # --cases: regenerate only these fixtures of t
 SECTIONS = {
     "keys": gen_keys,
     "schedules": gen_schedules, "pointwise": gen_pointwise, "units": gen_units,
-    "forward": gen_forward, "loops": gen_loops, "long_loops": gen_long_loops,
+    "forward": gen_forward, "loops": gen_loops, "horizons": gen_horizons, "long_loops": gen_long_loops,
     "proj_loops": gen_proj_loops, "options": gen_options, "training": gen_training,
     "guidance": gen_guidance, "guidance_short": gen_guidance_short, "grads": gen_grads,
     "projection": gen_projection, "glue": gen_glue, "sysid": gen_sysid,

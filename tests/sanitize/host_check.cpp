@@ -31,6 +31,7 @@ struct Arch {
     bool pack;      // also load synthetic weights and build the packed images
     int ks = 5;     // TemporalUnet(kernel_size): 3, 5 or 7
     std::vector<int> real = {};   // dad_model_set_group_channels: level widths before zero-padding the groups
+    int hreal = 0;                // dad_model_set_horizon: horizon before zero-padding (0: as given)
 };
 
 static float synth(uint64_t& state) {       // cheap deterministic values in (-1, 1)
@@ -69,8 +70,22 @@ static void check_arch(const Arch& a, int precision) {
     int rc = check_cfg(&c);
     if (rc != DAD_OK) { printf("  %-14s refused: %s\n", a.name, g_err); return; }
     for (size_t i = 0; i < a.real.size(); ++i) m.real_channels[i] = a.real[i];
+    m.real_horizon = a.hreal;
     rc = build_plan(&m);
     if (rc != DAD_OK) { printf("  %-14s refused: %s\n", a.name, g_err); return; }
+    if (a.hreal > 0) {
+        int masked = 0;
+        for (const ConvOp& op : m.plan.convs) {
+            const int rows = op.kind == CONV_DOWN ? op.Lout : op.Lin;        // GEMM rows per sample
+            CHECK(op.lreal >= 0 && op.lreal < rows + 1, "%s: lreal %d of %d", op.name.c_str(), op.lreal, rows);
+            if (op.lreal > 0) ++masked;
+            if (op.src0 == -2) CHECK(op.src_len == a.hreal, "%s: external rows %d", op.name.c_str(), op.src_len);
+            else CHECK(op.src_len == 0, "%s: src_len on an internal tensor", op.name.c_str());
+        }
+        CHECK(masked == (int)m.plan.convs.size(), "%d of %zu convs know their real length", masked, m.plan.convs.size());
+        CHECK(training_refusal(m) != nullptr, "padded horizon accepted for training");
+        CHECK(!cc_plan(m, 1).ok, "padded horizon took the small-batch kernels");
+    }
     if (!a.real.empty()) {
         int padded_ops = 0;
         for (const ConvOp& op : m.plan.convs) {
@@ -405,6 +420,9 @@ int main(int argc, char** argv) {
         {"shrink_k7", 5, 32, 32, 32, {1, 4, 2}, true, 7},
         {"d48_padded", 6, 64, 48, 32, {1, 2}, true, 5, {48, 96}},          // --dim 48 as the engine runs it
         {"d40_padded", 5, 64, 40, 32, {1, 2, 2}, true, 5, {40, 80, 120}},   // 40 / 80 / 120 -> 64 / 128 / 128
+        {"h24_padded", 6, 32, 32, 32, {1, 2, 4}, true, 5, {}, 24},          // horizon 24 as the engine runs it (32)
+        {"h100_padded", 11, 64, 64, 128, {1, 2, 4}, true, 5, {}, 100},      // 100 / 50 / 25 positions in 128 / 64 / 32
+        {"h48_d48", 6, 64, 48, 64, {1, 2}, true, 3, {48, 96}, 48},          // both paddings + kernel_size 3
     };
     // the fuzz generator's space (tests/fuzz_parity.py), deterministic sweep
     std::mt19937 rng(7);

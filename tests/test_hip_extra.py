@@ -567,6 +567,12 @@ def test_graph_replay_with_inkernel_noise(dev):
     (5, 40, (1, 2, 3), 32, 2),         #   40 / 80 / 120 -> 64 / 128 / 128: two levels share a padded width
     (7, 8, (1, 2), 16, 1),             #   one-channel groups (dim 8) at batch 1: split-K + padding
     (6, 48, (1, 2), 32, 9, 3),         #   ... with kernel_size 3
+    (6, 128, (1, 2, 4), 24, 40),       # horizon 24 on the PointMaze widths (24 / 12 / 6 positions, zero-padded to 32 / 16 / 8)
+    (11, 64, (1, 2, 4), 100, 3),       # horizon 100: 100 / 50 / 25 positions in 128-position tiles
+    (23, 256, (1, 4, 8), 48, 2),       # horizon 48 on the HalfCheetah widths (wide-group tiles, split-K)
+    (6, 48, (1, 2), 48, 5, 3),         # zero-padded horizon AND widths AND kernel_size 3
+    (9, 32, (1, 2, 2, 4), 8, 70),      # horizon 8 on four levels: ONE position at the deepest level (padded to 32 / 16 / 8 / 4)
+    (6, 32, (1, 2, 4, 8), 16, 4),      # the reference's default dim_mults at train.py's default horizon 16: 16 / 8 / 4 / 2
 ], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}" + (f"_k{a[5]}" if len(a) > 5 else ""))
 def test_assorted_architectures_match_oracle(arch, dev):
     """Shapes outside the three BASELINE architectures, against the oracle on seeded inputs."""
@@ -686,7 +692,7 @@ def test_projector_refuses_a_batch_of_another_shape(dev):
 def test_unsupported_architectures_are_refused_with_a_message(dev):
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
     from dynamics_aware_diffusion_amd._engine import DadError
-    for kwargs, H in ((dict(dim=32, dim_mults=(1, 2, 4, 8)), 16),     # 16 / 8 = 2 < 4
+    for kwargs, H in ((dict(dim=32, dim_mults=(1, 2, 4, 8)), 12),     # 12 cannot be halved three times (nor can the reference)
                       (dict(dim=44, dim_mults=(1, 2)), 32),           # GroupNorm(8, 44) does not exist in the reference either
                       (dict(dim=32, dim_mults=(1, 2), kernel_size=4), 32),   # even kernel: the reference's padding k//2 changes the length
                       (dict(dim=32, dim_mults=(1, 2), kernel_size=9), 32)):

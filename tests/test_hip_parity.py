@@ -115,6 +115,39 @@ def test_unet_forward_vs_reference(case, dev):
     assert err64 <= 2 * ref64 + 5e-7
 
 
+@pytest.mark.parametrize("case", cases.HORIZON_CASES, ids=lambda c: c[0])
+def test_non_power_of_two_horizons_vs_reference(case, dev):
+    """Horizons 24 / 12 / 40 (temporal_unet.py:35-54 takes any length every level can halve): the engine runs them
+    zero-padded to 32 / 16 / 64 (dad_model_set_horizon: zero rows behind the real ones, masked GroupNorm statistics,
+    trajectory tensors in their real shape) — forward and a conditioned loop against the reference's own run."""
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, GuidedPolicy, TemporalUnet
+    name, net, Hz, B, t = case
+    g = golden(name)
+    od_, ad_, td, dim, mults = cases.net_dims(net)
+    T = cases.NETS[net][4]
+    unet = TemporalUnet(td, dim=dim, dim_mults=mults)
+    unet.load_state_dict({k: torch.from_numpy(v) for k, v in cases.net_weights(net).items()})
+    diff = GaussianDiffusion(unet, Hz, od_, ad_, n_timesteps=T).to(dev)
+    x, noise = cases.horizon_inputs(name, net, Hz, B, T)
+    got = diff.model(torch.from_numpy(x).to(dev), t).cpu().numpy()
+    assert got.shape == g["eps"].shape
+    assert max_abs(got, g["eps"]) <= TOL_STEP
+    assert max_abs(got, g["eps_fp64"]) <= 2 * max_abs(g["eps"], g["eps_fp64"]) + 5e-7
+    assert diff._engine(dev).rows_padded and diff._engine(dev).small_batch_plan(B) == (0, 0)
+    pol = GuidedPolicy(diff, None)
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net)).to(dev)}
+    with injected_noise(noise, dev):
+        xf = pol.sample_loop(batch_size=B, conditions=cond)
+    torch.cuda.synchronize()
+    assert max_abs(xf.cpu().numpy(), g["x_final"]) <= TOL_LOOP
+    # in-kernel Philox noise at the real shape: deterministic, finite, inpainted row exact
+    diff.sampler_rng, diff.seed = "philox", 5
+    a = pol.sample_loop(batch_size=B, conditions=cond).cpu().numpy()
+    b = pol.sample_loop(batch_size=B, conditions=cond).cpu().numpy()
+    assert a.shape == (B, Hz, td) and np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.array_equal(a[:, 0], np.repeat(cond[0].cpu().numpy(), B, 0))
+
+
 @pytest.mark.parametrize("case", cases.LOOP_CASES, ids=lambda c: c[0])
 def test_sampling_loops_vs_reference(case, dev):
     name, net, T, n_steps, B, conditioned, schedule = case

@@ -125,6 +125,26 @@ def test_zero_padded_groups_keep_every_real_weight():
     lib.dad_model_destroy(h)
 
 
+def test_horizon_padding_entry_point():
+    """dad_model_set_horizon: the padded (power-of-two) horizon lives in dad_cfg, the real one must be a multiple of
+    2^(levels-1) below it; such models refuse training."""
+    import ctypes as C
+    from dynamics_aware_diffusion_amd import _engine
+    lib = _engine.load_library()
+    cfg = _pointmaze_cfg()                      # 3 levels, horizon 32
+    h = C.c_void_p()
+    assert lib.dad_model_create(C.byref(cfg), C.byref(h)) == 0
+    for bad in (0, 2, 22, 36, -4):              # below 2^(levels-1), not a multiple of 4, above the padded horizon
+        assert lib.dad_model_set_horizon(h, bad) == -1, bad
+    assert lib.dad_model_set_horizon(h, 24) == 0
+    assert lib.dad_model_set_training(h, 1) == -1 and b"horizon" in lib.dad_last_error()
+    assert lib.dad_model_set_horizon(h, 32) == 0          # back to the unpadded model
+    assert lib.dad_model_set_training(h, 1) == 0
+    lib.dad_model_destroy(h)
+    with pytest.raises(ValueError, match="halved"):
+        _engine.HipEngine(transition_dim=6, dim=32, channels=(32, 64, 128), horizon=22, n_timesteps=10)
+
+
 def test_planner_and_kernel_registry_agree():
     """The planner refuses launches no kernel was compiled for from its own statement of the registry
     (csrc/host_plan.hpp kernel_registered — what the sanitizer harness checks launch plans against); the two
@@ -229,7 +249,7 @@ def test_device_kernels_use_no_scratch(tmp_path):
     spilled = {n: int(b) for n, b in kernels if int(b) > 0}
     allowed = {n for n in spilled if "conv_cc" in n and "ELb1ELi" in n and spilled[n] <= 32}   # BIG variants
     # kernel_size=7 on 2048-channel layers (no recipe uses it): the direct-B tile rolls seven taps' fragments
-    allowed |= {n for n in spilled if "conv_gemm_f32ILi256ELi32ELi1ELi32ELi7E" in n and spilled[n] <= 64}
+    allowed |= {n for n in spilled if "conv_gemm_f32ILi256ELi32ELi1ELi32ELi7E" in n and spilled[n] <= 96}
     assert set(spilled) == allowed, {n: b for n, b in spilled.items() if n not in allowed}
     assert text.count("v_mfma_f32_32x32x2") > 1000 and text.count("v_mfma_f32_16x16x4") > 50
 

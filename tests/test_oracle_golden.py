@@ -74,6 +74,22 @@ def test_unet_forward(case):
     assert max_abs(eps64.numpy(), g["eps_fp64"]) <= 1e-12
 
 
+@pytest.mark.parametrize("case", cases.HORIZON_CASES, ids=lambda c: c[0])
+def test_non_power_of_two_horizons(case):
+    """The restatement at horizons 24 / 12 / 40 (any length every level can halve) against the reference."""
+    name, net, Hz, B, t = case
+    g = golden(name)
+    w = net_weights_torch(net)
+    T = cases.NETS[net][4]
+    x, noise = cases.horizon_inputs(name, net, Hz, B, T)
+    with torch.no_grad():
+        eps = od.unet_forward(w, torch.from_numpy(x), torch.full((B,), t, dtype=torch.long))
+    assert max_abs(eps.numpy(), g["eps"]) <= TOL
+    cond = {0: torch.from_numpy(cases.loop_condition(name, net))}
+    xf = od.sample_loop(w, od.schedule_buffers("cosine", T), torch.from_numpy(noise), T, cond)
+    assert max_abs(xf.numpy(), g["x_final"]) <= 5e-6
+
+
 @pytest.mark.parametrize("case", cases.LOOP_CASES, ids=lambda c: c[0])
 def test_sampling_loops(case):
     name, net, T, n_steps, B, conditioned, schedule = case
