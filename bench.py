@@ -499,15 +499,17 @@ def main() -> None:
         # steady state: steps issued back to back as a training loop does (the host side of step i + 1 runs under
         # the kernels of step i); forward_ms / backward_ms above are each bracketed by a synchronisation
         n_steady = 10
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_steady):
-            for prm in diff.parameters():
-                prm.grad = None
-            with torch.enable_grad():
-                diff.loss(x0).backward()
-        torch.cuda.synchronize()
-        steady = (time.perf_counter() - t0) / n_steady
+        steady = None
+        for timed in (False, True):                # (two untimed steps first: the allocator settles on the pattern
+            torch.cuda.synchronize()               #  of several steps in flight)
+            t0 = time.perf_counter()
+            for _ in range(n_steady if timed else 2):
+                for prm in diff.parameters():
+                    prm.grad = None
+                with torch.enable_grad():
+                    diff.loss(x0).backward()
+            torch.cuda.synchronize()
+            steady = (time.perf_counter() - t0) / n_steady
         # ... and with an optimiser step in the loop: every parameter changes, the next forward re-derives the
         # engine's packed copies on the device (dad_model_refresh_weights: one repack launch + one copy launch)
         opt = torch.optim.SGD(diff.parameters(), lr=1e-6)
