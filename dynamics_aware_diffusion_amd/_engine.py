@@ -218,10 +218,7 @@ class HipEngine:
                                  f"H % 2^(levels-1) == 0, temporal_unet.py:35-54)")
             if transition_dim == self.real_dim:
                 raise NotImplementedError("transition_dim == dim with a zero-padded horizon has no kernel")
-            if training:
-                raise NotImplementedError(f"horizon {horizon} runs zero-padded to {self.padded_horizon} (inference only): "
-                                          "train with a power-of-two horizon")
-        self.padded = self.padded or self.rows_padded      # (either kind: no training, no device-side refresh)
+        self.padded = self.padded or self.rows_padded
         cfg = DadCfg()
         cfg.transition_dim = transition_dim
         cfg.dim = padded[0] if padded != self.real_channels else dim

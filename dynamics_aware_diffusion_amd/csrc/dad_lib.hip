@@ -171,6 +171,8 @@ void reg_tile_padded(KernTable& t) {
     reg_kernel<CFG, 3, 1, false, false, false, true>(t);
     reg_kernel<CFG, 7, 1, false, false, false, true>(t);
     reg_kernel<CFG, 3, 2, false, false, false, true>(t);
+    if constexpr (Tile<CFG>::KC >= 16)                      // backward of Upsample1d
+        reg_kernel<CFG, 5, 2, false, false, false, true>(t);
     reg_kernel<CFG, 2, 1, false, false, false, true>(t);
     reg_kernel<CFG, 1, 1, false, false, false, true>(t);
     if constexpr (Tile<CFG>::KC < 16) {
@@ -1357,6 +1359,7 @@ TrainScratch train_scratch(const dad_model& m, int B) {
     }
     t.wslab = ws; t.tmp = tmp; t.bslab = bs;
     t.dxpad = (long)B * H * round_up(td, 32);
+    if (m.real_horizon > 0 && m.real_horizon != H) t.dxpad += 2L * B * H * round_up(td, 4);      // zero-padded copies of x and d out
     auto al = [](long v) { return (v + 63) / 64 * 64; };
     t.mirror = al(t.mirror); t.part = al(t.part); t.wslab = al(t.wslab); t.dxpad = al(t.dxpad);
     t.tmp = al(t.tmp); t.bslab = al(t.bslab);
@@ -1368,6 +1371,26 @@ size_t train_saved_bytes(const dad_model& m, int B) {
     return ((size_t)m.tplan.floats_per_sample * (size_t)B + (size_t)slab_floats_for(m, B)) * sizeof(float);
 }
 
+// dst[b][l][c] (l < Hp) = l < Hr ? src[b][l][c] : 0      (the trajectory into the zero-padded layout)
+__global__ void pad_rows_kernel(float* dst, const float* src, long B, int Hp, int Hr, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Hp * cols) return;
+    const int c = (int)(i % cols);
+    const long r = i / cols;
+    const int l = (int)(r % Hp);
+    const long b = r / Hp;
+    dst[i] = l < Hr ? src[(b * Hr + l) * cols + c] : 0.0f;
+}
+// dst[b][l][c] (l < Hr, c < cols) = src[(b * Hp + l) * ld + c]
+__global__ void slice_rows_cols_kernel(float* dst, const float* src, long B, int Hp, int Hr, int cols, int ld) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Hr * cols) return;
+    const int c = (int)(i % cols);
+    const long r = i / cols;
+    const int l = (int)(r % Hr);
+    const long b = r / Hr;
+    dst[i] = src[(b * Hp + l) * ld + c];
+}
 __global__ void slice_cols_kernel(float* dst, const float* src, long rows, int cols, int ld) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
@@ -1445,6 +1468,18 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
     for (size_t i = 0; i < convs.size(); ++i) owner[convs[i].dst] = (int)i;
     bool dx_written = false;
     auto G = [&](const std::string& key) -> float* { return grad_tensors[m->grad_index.at(key)]; };
+    // zero-padded horizon: the trajectory and d loss / d out arrive in their real shape (B, H_real, td); the pass runs on
+    // copies in the padded layout (zero rows behind the real ones), d x goes back through the same row map
+    const int Hr = traj_horizon(m);
+    if (Hr != H) {
+        float* const xpad = dxpad + (long)B * H * tdp;
+        float* const dopad = xpad + (long)B * H * round_up(td, 4);
+        const long n = (long)B * H * td;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xpad, x, (long)B, H, Hr, td);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dopad, d_out, (long)B, H, Hr, td);
+        HIP_TRY(hipGetLastError());
+        x = xpad; d_out = dopad;
+    }
 
     // y += x over n floats (n a multiple of 4), or y = x when y holds nothing yet
     auto accumulate = [&](float* y, const float* xs, long n, bool have) -> int {
@@ -1549,7 +1584,7 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
             gp.part_dgamma = part_take(f.cout); gp.part_dbeta = part_take(f.cout); gp.part_dbias = part_take(f.cout);
             gp.dtemb = f.temb_off >= 0 ? d_temb_rows + f.temb_off : nullptr;
             gp.temb_stride = P.temb_width;
-            gp.C = f.cout; gp.L = f.Lout; gp.cpg = f.cout / 8;
+            gp.C = f.cout; gp.L = f.Lout; gp.cpg = f.cout / 8; gp.lreal = f.lreal;
             gp.B = B;
             {   // one wave per (sample, group) pair while the pair fits its registers, else one block per pair
                 const int f4 = gp.cpg / 4 * gp.L;
@@ -1601,8 +1636,11 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
     }
     if (d_x != nullptr) {
         if (!dx_written) return fail(DAD_E_STATE, "backward: no gradient reached the trajectory");
-        const long n = (long)B * H * td;
-        hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, dxpad, (long)B * H, td, tdp);
+        const long n = (long)B * Hr * td;
+        if (Hr != H)
+            hipLaunchKernelGGL(slice_rows_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, dxpad, (long)B, H, Hr, td, tdp);
+        else
+            hipLaunchKernelGGL(slice_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, dxpad, (long)B * H, td, tdp);
         HIP_TRY(hipGetLastError());
     }
     return DAD_OK;

@@ -78,6 +78,7 @@ struct ConvOp {
     int lreal = 0;           // > 0: GEMM output rows per sample that exist (dad_model_set_horizon: the rest are zero
                              //      padding: masked in the GroupNorm statistics, stored as zeros); 0: all of them
     int src_len = 0;         // > 0: rows per sample of the EXTERNAL src0 (the trajectory keeps its real horizon)
+    int real_in = 0, real_out = 0;   // zero-padded horizon: real positions per sample of the input / output TENSOR (0: no padding)
     // device tensors (owned by the model)
     float* d_w = nullptr;
     float* d_bias = nullptr;
@@ -287,6 +288,8 @@ inline int build_plan_into(HostModel* m, Plan& P, bool retain) {
             const int lp_out = kind == CONV_DOWN ? Lin / 2 : Lin;
             if (lr_out != lp_out) op.lreal = lr_out;
             if (src0 == -2) op.src_len = Lr_now;
+            op.real_in = Lr_now;
+            op.real_out = kind == CONV_DOWN ? Lr_now / 2 : kind == CONV_UP ? 2 * Lr_now : Lr_now;
         }
         op.cin0 = cin0; op.cin1 = cin1;
         op.kc = (!norm.empty() && cout / 8 >= 256) ? 8 : 16;
@@ -502,6 +505,15 @@ inline int build_backward_plan(HostModel* m) {
                 slot(f.name + ".weight", (long)cin * f.cout * 4);
                 break;
         }
+        // zero-padded horizon: the data gradient is zero-padded like every activation (its launches store zeros
+        // behind the real rows: real GEMM rows = the forward conv's INPUT positions; the down-sampling conv's
+        // data gradient is a transposed conv whose GEMM rows are the forward OUTPUT positions)
+        for (int s = 0; s < b.n; ++s) {
+            const int real_rows = f.kind == CONV_DOWN ? f.real_out : f.real_in;
+            const int rows = f.kind == CONV_DOWN ? f.Lout : f.Lin;
+            b.op[s].lreal = (real_rows > 0 && real_rows != rows) ? real_rows : 0;
+            b.op[s].net_padded = f.net_padded;
+        }
         slot(f.name + ".bias", f.cout);
         if (!f.norm.empty()) { slot(f.norm + ".weight", f.cout); slot(f.norm + ".bias", f.cout); }
         m->max_cout = std::max(m->max_cout, f.cout);
@@ -511,6 +523,7 @@ inline int build_backward_plan(HostModel* m) {
         ConvOp f;
         f.name = "final_conv.1";
         m->bfinal = make_bwd_op(f, ".dgrad0", CONV_1X1, 1, 1, m->cfg.transition_dim, m->cfg.dim, m->cfg.horizon, m->cfg.horizon);
+        if (m->real_horizon > 0 && m->real_horizon != m->cfg.horizon) { m->bfinal.lreal = m->real_horizon; m->bfinal.net_padded = true; }
         slot("final_conv.1.weight", (long)m->cfg.transition_dim * m->cfg.dim);
         slot("final_conv.1.bias", m->cfg.transition_dim);
     }
@@ -521,7 +534,6 @@ inline const char* training_refusal(const HostModel& m) {
     if (m.precision != DAD_PREC_FP32) return "the backward pass exists for the fp32 arithmetic only";
     for (const ConvOp& op : m.tplan.convs)
         if (op.gn_real > 0) return "widths that are not a multiple of 32 with a power-of-two C/8 run on zero-padded GroupNorm groups: inference only";
-    if (m.real_horizon > 0 && m.real_horizon != m.cfg.horizon) return "a horizon that is not a power of two runs zero-padded: inference only";
     for (const ConvOp& op : m.tplan.convs)
         if (op.cat0 >= 0) return "identity residual over a channel concat (shrinking dim_mults) has no backward kernel";
     return nullptr;
@@ -883,7 +895,7 @@ inline bool fused_at(const HostModel& m, const ConvOp& op, int batch) {
 // dad_debug_kernel_table_consistent() compares the two).
 inline bool kernel_registered(int cfg, int taps, int stride, bool x3, bool bdir, bool ragged, bool res, bool padded = false) {
     if (cfg < 0 || cfg >= kNumTiles) return false;
-    if (padded && (!kPaddedTiles[cfg] || x3 || res || (stride == 2 && taps != 3))) return false;
+    if (padded && (!kPaddedTiles[cfg] || x3 || res)) return false;
     const bool kc16 = kTiles[cfg].KC >= 16;
     const bool k357 = taps == 3 || taps == 5 || taps == 7;
     if (ragged && !(stride == 1 && (k357 || taps == 1) && !bdir)) return false;

@@ -543,6 +543,8 @@ struct GnBwdParams {
     int32_t temb_stride;
     int32_t C, L, cpg;
     int32_t B;
+    int32_t lreal;        // > 0: only the first lreal positions of a sample exist (zero-padded horizon): the rest take no part
+                          // in the sums and get dH = 0
 };
 
 __device__ __forceinline__ float mish_grad_f32(float u) {
@@ -567,11 +569,12 @@ __global__ __launch_bounds__(GNB_THREADS) void gn_mish_bwd_kernel(const GnBwdPar
     const int cbase = g * cpg + 4 * q;
     const float mean = p.stats[((long)b * 8 + g) * 2], rstd = p.stats[((long)b * 8 + g) * 2 + 1];
     const float4 gam = ldg4(p.gamma + cbase), bet = ldg4(p.beta + cbase);
-    const float inv_n = 1.0f / (float)(cpg * L);
+    const int Lr = p.lreal > 0 ? p.lreal : L;
+    const float inv_n = 1.0f / (float)(cpg * Lr);
 
     // pass 1: the two pair sums
     float s1 = 0.0f, s2 = 0.0f;
-    for (int l = lg; l < L; l += nlg) {
+    for (int l = lg; l < Lr; l += nlg) {
         const long off = ((long)b * L + l) * C + cbase;
         const float4 hv = ldg4(p.h + off), da = ldg4(p.dA + off);
         const float xh[4] = {(hv.x - mean) * rstd, (hv.y - mean) * rstd, (hv.z - mean) * rstd, (hv.w - mean) * rstd};
@@ -596,7 +599,9 @@ __global__ __launch_bounds__(GNB_THREADS) void gn_mish_bwd_kernel(const GnBwdPar
     // pass 2: dH and the per-channel sums of this sample
     float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, pbias[4] = {0.f, 0.f, 0.f, 0.f},
           pt[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int l = lg; l < L; l += nlg) {
+    for (int l = Lr + lg; l < L; l += nlg)        // zero-padded horizon: the padding's gradient is zero
+        *reinterpret_cast<float4*>(p.dH + ((long)b * L + l) * C + cbase) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = lg; l < Lr; l += nlg) {
         const long off = ((long)b * L + l) * C + cbase;
         const float4 hv = ldg4(p.h + off), da = ldg4(p.dA + off);
         const float xh[4] = {(hv.x - mean) * rstd, (hv.y - mean) * rstd, (hv.z - mean) * rstd, (hv.w - mean) * rstd};
@@ -663,7 +668,8 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_wave_kernel(const GnBwdParams
     const float mean = p.stats[((long)b * 8 + g) * 2], rstd = p.stats[((long)b * 8 + g) * 2 + 1];
     const float4 gam = ldg4(p.gamma + cbase), bet = ldg4(p.beta + cbase);
     const float gm[4] = {gam.x, gam.y, gam.z, gam.w}, bt[4] = {bet.x, bet.y, bet.z, bet.w};
-    const float inv_n = 1.0f / (float)(cpg * L);
+    const int Lr = p.lreal > 0 ? p.lreal : L;      // positions that exist (zero-padded horizon)
+    const float inv_n = 1.0f / (float)(cpg * Lr);
 
     float4 hv[NV], da[NV];
     long off[NV];
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_wave_kernel(const GnBwdParams
     float pt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const bool live = v * 64 + lane < count;
+        const bool live = v * 64 + lane < count && ((v * 64 + lane) >> nq_shift) < Lr;
         float x[4] = {hv[v].x, hv[v].y, hv[v].z, hv[v].w}, d[4] = {da[v].x, da[v].y, da[v].z, da[v].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -699,7 +705,8 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_wave_kernel(const GnBwdParams
     float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, pbias[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const bool live = v * 64 + lane < count;
+        const bool inside = v * 64 + lane < count;                                 // an element of the pair
+        const bool live = inside && ((v * 64 + lane) >> nq_shift) < Lr;            // ... at a position that exists
         const float x[4] = {hv[v].x, hv[v].y, hv[v].z, hv[v].w}, d[4] = {da[v].x, da[v].y, da[v].z, da[v].w};
         float dh[4];
 #pragma unroll
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_wave_kernel(const GnBwdParams
             pb[j] += d[j];
             pbias[j] += dh[j];
         }
-        if (live) *reinterpret_cast<float4*>(p.dH + off[v]) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+        if (inside) *reinterpret_cast<float4*>(p.dH + off[v]) = make_float4(dh[0], dh[1], dh[2], dh[3]);   // (padding: zeros)
     }
     for (int s = nq; s < 64; s <<= 1)              // lanes q, q + nq, q + 2 nq, ... hold the same channels
 #pragma unroll

@@ -134,7 +134,7 @@ class TemporalUnet(nn.Module):
         if self._engine is not None and sig == self._engine_sig and (self._engine.training or not training):
             if params == self._engine_params:
                 return self._engine
-            if self.precision == "fp32" and not self._engine.padded and all(p.device == device for p in self.parameters()):
+            if self.precision == "fp32" and not self._engine.widths_padded and all(p.device == device for p in self.parameters()):
                 # only parameter VALUES changed (an optimiser step): the packed copies are re-derived on the
                 # device, no engine rebuild and no host round trip
                 self._engine.refresh(dict(self.named_parameters()))

@@ -119,7 +119,7 @@ int dad_model_set_group_channels(dad_model* m, const int32_t* real_channels, int
  * layout with ZERO rows behind the real ones (exactly the zero padding a conv sees at the end of a sample), the
  * GroupNorm statistics count the real rows only, and the external tensors (x, noise, guide gradient, outputs) keep
  * the real shape (B, real_horizon, transition_dim).  Call between dad_model_create and dad_model_finalize.  Such models
- * run the batch kernels at every batch size and are refused by dad_model_set_training. */
+ * run the batch kernels at every batch size; they train (the data gradients are zero-padded the same way). */
 int dad_model_set_horizon(dad_model* m, int32_t real_horizon);
 /* Checks every tensor is present, builds the per-timestep time-embedding tables
  * (SinusoidalPosEmb + time_mlp + every block's Mish->Linear, temporal_unet.py:19-32,

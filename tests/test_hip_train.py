@@ -214,6 +214,10 @@ def test_sgd_steps_track_the_oracle_without_leaving_the_device(dev):
     (6, 64, (1, 2, 4), 32, 5, 3),      # TemporalUnet(kernel_size=3) (temporal_unet.py:139): 3-tap forward, flipped 3-tap data gradient, wgrad<3>
     (7, 32, (1, 4), 16, 3, 7),         # kernel_size=7: halo of three rows per sample side, wgrad<7>
     (5, 256, (1, 8), 8, 2, 3),         # kernel_size=3 on 2048 channels: the LDS-staged <256,32> tile (the direct-B kernel is 5-tap only)
+    (6, 64, (1, 2, 4), 24, 5),         # horizon 24 (zero-padded to 32): masked GroupNorm backward, zero-padded data gradients,
+    (9, 32, (1, 2, 2, 4), 40, 3),      #   the trajectory and d loss / d out in their real shape; 40 on four levels
+    (7, 32, (1, 2, 4, 8), 16, 6),      # the reference's default dim_mults at train.py's default horizon 16 (2 positions at the bottom)
+    (6, 128, (1, 2), 100, 2, 3),       # horizon 100 with kernel_size 3
 ], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}" + (f"_k{a[5]}" if len(a) > 5 else ""))
 def test_gradients_on_other_architectures_vs_oracle(arch, dev):
     """The backward pass beyond the fixture nets: wide GroupNorm groups (the direct-B forward tile keeps the
