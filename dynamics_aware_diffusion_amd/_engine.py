@@ -200,10 +200,6 @@ class HipEngine:
                 raise NotImplementedError(
                     f"transition_dim == dim == {dim} makes the first block's residual the trajectory itself; "
                     "with zero-padded GroupNorm groups that identity has no kernel")
-            if training:
-                raise NotImplementedError(
-                    f"level widths {self.real_channels} run on zero-padded GroupNorm groups (inference only): "
-                    "train with widths that are a multiple of 32 with a power-of-two C / 8")
         # horizons every level can halve but that are not a power of two (24, 48, 96, 100 ...) run zero-padded to
         # the next power of two (dad_model_set_horizon); the trajectory tensors keep their real shape
         horizon = int(horizon)
@@ -269,6 +265,7 @@ class HipEngine:
         if self.widths_padded:
             from .utils import padding
             mults = [c // self.real_dim for c in self.real_channels]
+            self._pad_plan, _, _ = padding.padding_plan(unet_state.keys(), self.transition_dim, self.real_dim, mults)
             unet_state, _, _ = padding.pad_unet_state(unet_state, self.transition_dim, self.real_dim, mults)
         keep = []
         for key, t in unet_state.items():
@@ -426,6 +423,12 @@ class HipEngine:
         """Re-derive the engine's packed copies from parameter tensors that already live on this device
         (fp32, contiguous): no host round trip (dad_model_refresh_weights)."""
         keys, ptrs, keep = [], [], []
+        if self.widths_padded:             # the padded tensors are rebuilt on the device: one scatter for all of them
+            with torch.no_grad():
+                names = list(unet_state.keys())
+                padded = self.flat_padding(names, [tuple(unet_state[k].shape) for k in names]).pad(
+                    [unet_state[k].detach().to(self.device) for k in names])
+            unet_state = dict(zip(names, padded))
         for key, t in unet_state.items():
             d = t.detach()
             if d.device != self.device or d.dtype != torch.float32 or not d.is_contiguous():
@@ -438,6 +441,32 @@ class HipEngine:
             _check(self.lib, self.lib.dad_model_refresh_weights(
                 self._h, n, (C.c_char_p * n)(*keys), (C.c_void_p * n)(*ptrs), self._stream()))
         self._refresh_keep = keep          # (stream-ordered: the copies run before anything enqueued later)
+
+    def flat_padding(self, keys, shapes):
+        """utils/padding.FlatPadding of the named tensors (real shapes) for this net's zero-padded widths."""
+        from .utils import padding
+        cache = self.__dict__.setdefault("_flat_paddings", {})
+        sig = tuple(keys)
+        if sig not in cache:
+            cache[sig] = padding.FlatPadding(keys, shapes, self._pad_plan)
+        return cache[sig]
+
+    def time_projection_index(self) -> torch.Tensor:
+        """Column of every real time-projection entry in the padded rows the training forward reads: the blocks'
+        projections side by side in launch order, each at its level's padded width."""
+        from .utils import padding
+        cached = getattr(self, "_temb_index", None)
+        if cached is None:
+            n = len(self.real_channels)
+            widths = [c for c in self.real_channels for _ in (0, 1)] + [self.real_channels[-1]] * 2
+            for j in range(n - 1):
+                widths += [self.real_channels[n - 2 - j]] * 2
+            index, off = [], 0
+            for c in widths:
+                index.append(padding.channel_index(c) + off)
+                off += padding.padded_width(c)
+            cached = self._temb_index = (torch.cat(index).to(self.device), off)
+        return cached
 
     def grad_layout(self):
         """[(reference key without 'model.', offset in floats, numel)] of the flat gradient buffer and

@@ -1584,7 +1584,7 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
             gp.part_dgamma = part_take(f.cout); gp.part_dbeta = part_take(f.cout); gp.part_dbias = part_take(f.cout);
             gp.dtemb = f.temb_off >= 0 ? d_temb_rows + f.temb_off : nullptr;
             gp.temb_stride = P.temb_width;
-            gp.C = f.cout; gp.L = f.Lout; gp.cpg = f.cout / 8; gp.lreal = f.lreal;
+            gp.C = f.cout; gp.L = f.Lout; gp.cpg = f.cout / 8; gp.lreal = f.lreal; gp.cpg_real = f.gn_real;
             gp.B = B;
             {   // one wave per (sample, group) pair while the pair fits its registers, else one block per pair
                 const int f4 = gp.cpg / 4 * gp.L;

@@ -533,8 +533,6 @@ inline int build_backward_plan(HostModel* m) {
 inline const char* training_refusal(const HostModel& m) {
     if (m.precision != DAD_PREC_FP32) return "the backward pass exists for the fp32 arithmetic only";
     for (const ConvOp& op : m.tplan.convs)
-        if (op.gn_real > 0) return "widths that are not a multiple of 32 with a power-of-two C/8 run on zero-padded GroupNorm groups: inference only";
-    for (const ConvOp& op : m.tplan.convs)
         if (op.cat0 >= 0) return "identity residual over a channel concat (shrinking dim_mults) has no backward kernel";
     return nullptr;
 }

@@ -545,6 +545,8 @@ struct GnBwdParams {
     int32_t B;
     int32_t lreal;        // > 0: only the first lreal positions of a sample exist (zero-padded horizon): the rest take no part
                           // in the sums and get dH = 0
+    int32_t cpg_real;     // > 0: channels of a group that exist (zero-padded groups: gamma = 0 on the padding keeps it out of
+                          // the two pair sums; only their divisor changes.  dH on the padding is not zero and meets zero weights)
 };
 
 __device__ __forceinline__ float mish_grad_f32(float u) {
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(GNB_THREADS) void gn_mish_bwd_kernel(const GnBwdPar
     const float mean = p.stats[((long)b * 8 + g) * 2], rstd = p.stats[((long)b * 8 + g) * 2 + 1];
     const float4 gam = ldg4(p.gamma + cbase), bet = ldg4(p.beta + cbase);
     const int Lr = p.lreal > 0 ? p.lreal : L;
-    const float inv_n = 1.0f / (float)(cpg * Lr);
+    const float inv_n = 1.0f / (float)((p.cpg_real > 0 ? p.cpg_real : cpg) * Lr);
 
     // pass 1: the two pair sums
     float s1 = 0.0f, s2 = 0.0f;
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_wave_kernel(const GnBwdParams
     const float4 gam = ldg4(p.gamma + cbase), bet = ldg4(p.beta + cbase);
     const float gm[4] = {gam.x, gam.y, gam.z, gam.w}, bt[4] = {bet.x, bet.y, bet.z, bet.w};
     const int Lr = p.lreal > 0 ? p.lreal : L;      // positions that exist (zero-padded horizon)
-    const float inv_n = 1.0f / (float)(cpg * Lr);
+    const float inv_n = 1.0f / (float)((p.cpg_real > 0 ? p.cpg_real : cpg) * Lr);
 
     float4 hv[NV], da[NV];
     long off[NV];

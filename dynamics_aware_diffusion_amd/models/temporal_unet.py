@@ -134,7 +134,7 @@ class TemporalUnet(nn.Module):
         if self._engine is not None and sig == self._engine_sig and (self._engine.training or not training):
             if params == self._engine_params:
                 return self._engine
-            if self.precision == "fp32" and not self._engine.widths_padded and all(p.device == device for p in self.parameters()):
+            if self.precision == "fp32" and all(p.device == device for p in self.parameters()):
                 # only parameter VALUES changed (an optimiser step): the packed copies are re-derived on the
                 # device, no engine rebuild and no host round trip
                 self._engine.refresh(dict(self.named_parameters()))
@@ -209,7 +209,15 @@ class TemporalUnet(nn.Module):
         layout, _ = eng.grad_layout()
         params = dict(self.named_parameters())
         rows = self._time_projections(time.reshape(-1).to(x.device))
-        return _UnetFunction.apply(eng, layout, x.contiguous().float(), rows, *[params[k] for k, _, _ in layout])
+        tensors = [params[k] for k, _, _ in layout]
+        if eng.widths_padded:
+            # zero-padded widths (utils/padding.py): the engine works on padded parameters and padded projection rows,
+            # built here with torch ops — autograd maps the padded gradients back onto the real parameters
+            names = [k for k, _, _ in layout]
+            tensors = eng.flat_padding(names, [tuple(t.shape) for t in tensors]).pad(tensors)
+            index, width = eng.time_projection_index()
+            rows = torch.zeros(rows.shape[0], width, dtype=rows.dtype, device=rows.device).index_copy(1, index, rows)
+        return _UnetFunction.apply(eng, layout, x.contiguous().float(), rows, *tensors)
 
     def forward(self, x: torch.Tensor, time: Union[int, torch.Tensor]) -> torch.Tensor:
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):

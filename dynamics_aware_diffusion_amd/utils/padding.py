@@ -34,19 +34,20 @@ def channel_index(channels: int) -> torch.Tensor:
 def _scatter(t: torch.Tensor, axis: int, index: torch.Tensor, size: int) -> torch.Tensor:
     shape = list(t.shape)
     shape[axis] = size
-    out = torch.zeros(shape, dtype=t.dtype)
+    out = torch.zeros(shape, dtype=t.dtype, device=t.device)
     out.index_copy_(axis, index, t)
     return out
 
 
-def pad_unet_state(state: Mapping[str, torch.Tensor], transition_dim: int, dim: int,
-                   dim_mults: Sequence[int]) -> Tuple[Dict[str, torch.Tensor], int, List[int]]:
-    """(padded state_dict, padded dim, padded level widths) of a TemporalUnet state_dict (reference keys
-    without ``model.``, temporal_unet.py:155-197).  Tensors of levels that need no padding pass through."""
+def padding_plan(keys, transition_dim: int, dim: int, dim_mults: Sequence[int]):
+    """key -> [(axis, index of every real entry along that axis in the padded tensor, padded size)] for every
+    tensor of a TemporalUnet state_dict (reference keys without ``model.``, temporal_unet.py:155-197), plus the
+    padded dim and level widths.  Keys of levels that need no padding get an empty list."""
     widths = [dim * m for m in dim_mults]
     padded = [padded_width(c) for c in widths]
     n = len(widths)
-    out: Dict[str, torch.Tensor] = {}
+    keys = set(keys)
+    plan: Dict[str, list] = {}
 
     def one(c: int):                       # (index, padded size) of a tensor of c channels
         return channel_index(c), padded_width(c)
@@ -61,36 +62,32 @@ def pad_unet_state(state: Mapping[str, torch.Tensor], transition_dim: int, dim: 
 
     def conv(key: str, cout, cin) -> None:
         """Conv1d weight (co, ci, k) + bias; cin: None = external (the trajectory: no padding) or widths."""
-        w, b = state[key + ".weight"].detach().cpu().float(), state[key + ".bias"].detach().cpu().float()
+        w, b = [], []
         if cout is not None:
             io, po = one(cout)
-            w, b = _scatter(w, 0, io, po), _scatter(b, 0, io, po)
+            w.append((0, io, po)); b.append((0, io, po))
         if cin is not None:
             ii, pi = cat(cin)
-            w = _scatter(w, 1, ii, pi)
-        out[key + ".weight"], out[key + ".bias"] = w, b
+            w.append((1, ii, pi))
+        plan[key + ".weight"], plan[key + ".bias"] = w, b
 
-    def norm(key: str, c: int) -> None:
+    def vec(key: str, c: int) -> None:
         i, p = one(c)
-        out[key + ".weight"] = _scatter(state[key + ".weight"].detach().cpu().float(), 0, i, p)
-        out[key + ".bias"] = _scatter(state[key + ".bias"].detach().cpu().float(), 0, i, p)
+        plan[key] = [(0, i, p)]
 
     def res_block(base: str, cin, cout: int) -> None:
         conv(base + ".blocks.0.block.0", cout, cin)
-        norm(base + ".blocks.0.block.1", cout)
+        vec(base + ".blocks.0.block.1.weight", cout); vec(base + ".blocks.0.block.1.bias", cout)
         conv(base + ".blocks.1.block.0", cout, [cout])
-        norm(base + ".blocks.1.block.1", cout)
-        i, p = one(cout)
-        out[base + ".time_mlp.1.weight"] = _scatter(state[base + ".time_mlp.1.weight"].detach().cpu().float(), 0, i, p)
-        out[base + ".time_mlp.1.bias"] = _scatter(state[base + ".time_mlp.1.bias"].detach().cpu().float(), 0, i, p)
-        if base + ".residual_conv.weight" in state:
+        vec(base + ".blocks.1.block.1.weight", cout); vec(base + ".blocks.1.block.1.bias", cout)
+        vec(base + ".time_mlp.1.weight", cout); vec(base + ".time_mlp.1.bias", cout)
+        if base + ".residual_conv.weight" in keys:
             conv(base + ".residual_conv", cout, cin)
 
     # time MLP: the sinusoid keeps its `dim` real columns in front (HipEngine pads the table the same way)
-    w1 = state["time_mlp.1.weight"].detach().cpu().float()
-    out["time_mlp.1.weight"] = _scatter(w1, 1, torch.arange(dim), padded[0])
+    plan["time_mlp.1.weight"] = [(1, torch.arange(dim), padded[0])]
     for k in ("time_mlp.1.bias", "time_mlp.3.weight", "time_mlp.3.bias"):
-        out[k] = state[k].detach().cpu().float()
+        plan[k] = []
 
     cx = None                              # the trajectory: transition_dim channels, never padded
     for i, co in enumerate(widths):
@@ -106,16 +103,81 @@ def pad_unet_state(state: Mapping[str, torch.Tensor], transition_dim: int, dim: 
         co = widths[lvl - 1]
         res_block(f"ups.{j}.0", [cx, widths[lvl]], co)
         res_block(f"ups.{j}.1", [co], co)
-        # ConvTranspose1d weight is (in, out, k)
-        key = f"ups.{j}.2.conv"
-        i, p = one(co)
-        out[key + ".weight"] = _scatter(_scatter(state[key + ".weight"].detach().cpu().float(), 0, i, p), 1, i, p)
-        out[key + ".bias"] = _scatter(state[key + ".bias"].detach().cpu().float(), 0, i, p)
+        i, p = one(co)                     # ConvTranspose1d weight is (in, out, k)
+        plan[f"ups.{j}.2.conv.weight"] = [(0, i, p), (1, i, p)]
+        plan[f"ups.{j}.2.conv.bias"] = [(0, i, p)]
         cx = co
     conv("final_conv.0.block.0", dim, [cx])
-    norm("final_conv.0.block.1", dim)
+    vec("final_conv.0.block.1.weight", dim); vec("final_conv.0.block.1.bias", dim)
     conv("final_conv.1", None, [dim])
-    missing = set(state) - set(out)
+    missing = keys - set(plan)
     if missing:
         raise KeyError(f"unexpected keys in the denoiser state_dict: {sorted(missing)[:4]}")
-    return out, padded[0], padded
+    return plan, padded[0], padded
+
+
+def pad_tensor(t: torch.Tensor, steps) -> torch.Tensor:
+    """The padded form of one tensor (zeros outside the real entries), on the tensor's own device."""
+    t = t.detach().float()
+    for axis, index, size in steps:
+        t = _scatter(t, axis, index.to(t.device), size)
+    return t.contiguous()
+
+
+def unpad_tensor(t: torch.Tensor, steps) -> torch.Tensor:
+    """The real entries of a tensor in the padded layout (the inverse of pad_tensor on them)."""
+    for axis, index, _ in steps:
+        t = t.index_select(axis, index.to(t.device))
+    return t.contiguous()
+
+
+def pad_unet_state(state: Mapping[str, torch.Tensor], transition_dim: int, dim: int,
+                   dim_mults: Sequence[int], device=None) -> Tuple[Dict[str, torch.Tensor], int, List[int]]:
+    """(padded state_dict, padded dim, padded level widths) of a TemporalUnet state_dict.  ``device``: where the padded
+    tensors should live (default: the host — what dad_model_load_weight takes; the GPU for a device-side refresh)."""
+    plan, pdim, widths = padding_plan(state.keys(), transition_dim, dim, dim_mults)
+    out: Dict[str, torch.Tensor] = {}
+    for key, t in state.items():
+        src = t.detach().float()
+        src = src.cpu() if device is None else src.to(device)
+        out[key] = pad_tensor(src, plan[key])
+    return out, pdim, widths
+
+
+class FlatPadding:
+    """Many tensors padded with ONE scatter: the real tensors are flattened side by side, one ``index_copy`` drops them
+    into a zero vector that holds the padded tensors side by side, ``split_with_sizes`` hands out the views.  Every step
+    is a torch op, so autograd maps the gradients of the padded tensors back onto the real ones (an ``index_select``) —
+    this is how a net of zero-padded widths trains: the engine sees padded parameters, the optimiser the real ones."""
+
+    def __init__(self, keys: Sequence[str], shapes: Sequence[Sequence[int]], plan: Mapping[str, list]):
+        self.keys = list(keys)
+        self.padded_shapes: List[Tuple[int, ...]] = []
+        index, off = [], 0
+        for key, shape in zip(self.keys, shapes):
+            ps = list(shape)
+            for axis, _, size in plan[key]:
+                ps[axis] = size
+            n = 1
+            for d in ps:
+                n *= d
+            where = unpad_tensor(torch.arange(n).view(ps), plan[key]).reshape(-1)
+            index.append(where + off)
+            self.padded_shapes.append(tuple(ps))
+            off += n
+        self.sizes = [int(torch.Size(s).numel()) for s in self.padded_shapes]
+        self.total = off
+        self.index = torch.cat(index) if index else torch.zeros(0, dtype=torch.long)
+        self._on: Dict[str, torch.Tensor] = {}
+
+    def index_on(self, device) -> torch.Tensor:
+        key = str(device)
+        if key not in self._on:
+            self._on[key] = self.index.to(device)
+        return self._on[key]
+
+    def pad(self, tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """The padded tensors (views of one new vector), in the order of ``keys``; differentiable."""
+        flat = torch.cat([t.reshape(-1) for t in tensors]).float()
+        wide = torch.zeros(self.total, dtype=torch.float32, device=flat.device).index_copy(0, self.index_on(flat.device), flat)
+        return [v.view(s) for v, s in zip(wide.split_with_sizes(self.sizes), self.padded_shapes)]

@@ -212,6 +212,8 @@ GRAD_CASES = [
     ("grads_pointmaze_B9", "pointmaze", 100, 9, "l2", True, False),
     ("grads_tiny_k3", "tiny_k3", 20, 5, "l2", True, False),
     ("grads_tiny_k7", "tiny_k7", 20, 4, "l2", True, True),
+    ("grads_tiny_d48", "tiny_d48", 20, 5, "l2", True, False),     # zero-padded GroupNorm groups (utils/padding.py)
+    ("grads_tiny_d24", "tiny_d24", 20, 4, "l1", True, True),
 ]
 GRAD_SAMPLE = 2048
 

@@ -91,7 +91,10 @@ static void check_arch(const Arch& a, int precision) {
             if (op.gn_real > 0) { ++padded_ops; CHECK(!op.norm.empty() && op.gn_real < op.cout / 8, "%s: gn_real %d of %d", op.name.c_str(), op.gn_real, op.cout / 8); }
         }
         CHECK(padded_ops > 0, "no conv knows its real group width");
-        CHECK(training_refusal(m) != nullptr, "padded groups accepted for training");
+        // (padded groups train: the training plan's convs know the real group width as well — the GroupNorm
+        // backward divides its pair means by it)
+        for (size_t i = 0; i < m.tplan.convs.size() && i < m.plan.convs.size(); ++i)
+            CHECK(m.tplan.convs[i].gn_real == m.plan.convs[i].gn_real, "%s: training plan lost gn_real", m.plan.convs[i].name.c_str());
         CHECK(!cc_plan(m, 1).ok, "padded groups took the small-batch kernels");
     }
     const Plan& P = m.plan;

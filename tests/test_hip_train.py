@@ -13,7 +13,7 @@ import torch
 
 from tests.golden import cases
 from tests.test_hip_parity import build, dev, injected_noise  # noqa: F401  (dev: fixture)
-from tests.util import golden, max_abs, net_weights_torch
+from tests.util import golden, grad_scales, max_abs, net_weights_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -150,22 +150,17 @@ def test_training_refusals(dev):
             diff.model(torch.zeros(2, cases.H, 6, device=dev), torch.zeros(2, dtype=torch.long, device=dev))
     finally:
         diff.model.precision = "fp32"
-    # zero-padded GroupNorm groups (widths that are not a multiple of 32 with a power-of-two C / 8): inference only
-    padded = build("tiny_d48", 20, "cosine", dev)
-    with torch.enable_grad(), pytest.raises(NotImplementedError, match="zero-padded"):
-        padded.model(torch.zeros(2, cases.H, 6, device=dev), torch.zeros(2, dtype=torch.long, device=dev))
-    with torch.no_grad():
-        assert padded.model(torch.zeros(2, cases.H, 6, device=dev), 3).shape == (2, cases.H, 6)
 
 
-def test_sgd_steps_track_the_oracle_without_leaving_the_device(dev):
+@pytest.mark.parametrize("net", ["tiny4", "tiny_d48"])   # (tiny_d48: zero-padded widths — the padded copies are rebuilt on the device too)
+def test_sgd_steps_track_the_oracle_without_leaving_the_device(net, dev):
     """Three optimiser steps (utils/training.py:152-166: loss, backward, step) on the HIP engine against the
     same three steps of torch autograd on the oracle.  After every step the engine re-derives its packed
     images on the device (dad_model_refresh_weights: forward images, data-gradient images, time tables) —
     the engine object must survive the steps — and the sampler's inference kernels must see the new weights."""
     from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
     from oracle import denoiser as orc
-    net, T, B, lr = "tiny4", 20, 5, 0.05
+    T, B, lr = 20, 5, 0.05
     od, ad, td, dim, mults = cases.net_dims(net)
     unet = TemporalUnet(td, dim=dim, dim_mults=mults)
     unet.load_state_dict({k: torch.from_numpy(v) for k, v in cases.net_weights(net).items()})
@@ -218,6 +213,9 @@ def test_sgd_steps_track_the_oracle_without_leaving_the_device(dev):
     (9, 32, (1, 2, 2, 4), 40, 3),      #   the trajectory and d loss / d out in their real shape; 40 on four levels
     (7, 32, (1, 2, 4, 8), 16, 6),      # the reference's default dim_mults at train.py's default horizon 16 (2 positions at the bottom)
     (6, 128, (1, 2), 100, 2, 3),       # horizon 100 with kernel_size 3
+    (6, 96, (1, 2, 4), 32, 4),         # --dim 96: groups of 12 / 24 / 48 channels run zero-padded to 16 / 32 / 64 (utils/padding.py)
+    (7, 40, (1, 3), 24, 3, 3),         # padded widths (40 -> 64, 120 -> 128) AND a padded horizon (24 -> 32), kernel_size 3
+    (5, 8, (1, 2, 4, 8), 16, 5),       # dim 8: one real channel per group at level 0
 ], ids=lambda a: f"td{a[0]}_d{a[1]}_m{'x'.join(map(str, a[2]))}_H{a[3]}_B{a[4]}" + (f"_k{a[5]}" if len(a) > 5 else ""))
 def test_gradients_on_other_architectures_vs_oracle(arch, dev):
     """The backward pass beyond the fixture nets: wide GroupNorm groups (the direct-B forward tile keeps the
@@ -251,8 +249,9 @@ def test_gradients_on_other_architectures_vs_oracle(arch, dev):
     _, og, odx = orc.training_gradients(w, orc.schedule_buffers("cosine", T), x0, t, noise)
     assert max_abs(x_t.grad.cpu().numpy(), odx.numpy()) <= REL * float(odx.abs().max())
     worst = 0.0
+    scales = grad_scales(og)
     for k, p in diff.model.named_parameters():
-        scale = max(float(og[k].abs().max()), 1e-12)
+        scale = scales[k]
         e = max_abs(p.grad.cpu().numpy(), og[k].numpy()) / scale
         worst = max(worst, e)
         assert e <= REL, f"{k}: {e:.2e} x max|g|"
