@@ -426,9 +426,15 @@ class HipEngine:
         if self.widths_padded:             # the padded tensors are rebuilt on the device: one scatter for all of them
             with torch.no_grad():
                 names = list(unet_state.keys())
-                padded = self.flat_padding(names, [tuple(unet_state[k].shape) for k in names]).pad(
-                    [unet_state[k].detach().to(self.device) for k in names])
-            unet_state = dict(zip(names, padded))
+                fp = self.flat_padding(names, [tuple(unet_state[k].shape) for k in names])
+                wide = fp.pad_flat([unet_state[k].detach().to(self.device) for k in names])
+            base, n = wide.data_ptr(), len(names)        # (FlatPadding's packed offsets are 16-byte aligned)
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.dad_model_refresh_weights(
+                    self._h, n, (C.c_char_p * n)(*[k.encode() for k in names]),
+                    (C.c_void_p * n)(*[base + 4 * o for o in fp.offsets]), self._stream()))
+            self._refresh_keep = [wide]
+            return
         for key, t in unet_state.items():
             d = t.detach()
             if d.device != self.device or d.dtype != torch.float32 or not d.is_contiguous():
@@ -442,13 +448,13 @@ class HipEngine:
                 self._h, n, (C.c_char_p * n)(*keys), (C.c_void_p * n)(*ptrs), self._stream()))
         self._refresh_keep = keep          # (stream-ordered: the copies run before anything enqueued later)
 
-    def flat_padding(self, keys, shapes):
+    def flat_padding(self, keys, shapes, offsets=None, total=None):
         """utils/padding.FlatPadding of the named tensors (real shapes) for this net's zero-padded widths."""
         from .utils import padding
         cache = self.__dict__.setdefault("_flat_paddings", {})
-        sig = tuple(keys)
+        sig = (tuple(keys), None if offsets is None else tuple(offsets))
         if sig not in cache:
-            cache[sig] = padding.FlatPadding(keys, shapes, self._pad_plan)
+            cache[sig] = padding.FlatPadding(keys, shapes, self._pad_plan, offsets, total)
         return cache[sig]
 
     def time_projection_index(self) -> torch.Tensor:
@@ -514,6 +520,15 @@ class HipEngine:
         layout, total = self.grad_layout()
         if len(shapes) != len(layout):
             raise RuntimeError(f"{len(shapes)} parameter shapes for {len(layout)} gradient tensors")
+        real = None
+        if self.widths_padded:
+            # zero-padded widths: the library fills padded gradients; `shapes` are the REAL parameters' — one gather
+            # over the flat buffer picks the real entries (utils/padding.FlatPadding), the padding's are dropped
+            real = self.flat_padding([k for k, _, _ in layout], shapes, [o for _, o, _ in layout], total)
+            shapes = real.padded_shapes
+            for (key, _, numel), n in zip(layout, real.sizes):
+                if n != numel:
+                    raise RuntimeError(f"{key}: {n} padded elements, the library expects {numel}")
         # ONE allocation per step, split into per-parameter views at the library's own (16-byte aligned) offsets:
         # autograd adopts a contiguous view as `.grad` as it does a tensor of its own (no copy), and the host side of
         # a step loses ~150 allocator calls
@@ -530,6 +545,8 @@ class HipEngine:
             _check(self.lib, self.lib.dad_unet_backward(
                 self._h, x.data_ptr(), d_out.data_ptr(), d_x.data_ptr(), d_temb.data_ptr(), ptrs, len(grads), B,
                 saved.data_ptr(), saved.numel() * 4, scratch.data_ptr(), scratch.numel() * 4, self._stream()))
+        if real is not None:
+            grads = real.gather(flat)
         return d_x, d_temb, grads
 
     # ------------------------------------------------------------------ test / tuning hooks

@@ -211,10 +211,8 @@ class TemporalUnet(nn.Module):
         rows = self._time_projections(time.reshape(-1).to(x.device))
         tensors = [params[k] for k, _, _ in layout]
         if eng.widths_padded:
-            # zero-padded widths (utils/padding.py): the engine works on padded parameters and padded projection rows,
-            # built here with torch ops — autograd maps the padded gradients back onto the real parameters
-            names = [k for k, _, _ in layout]
-            tensors = eng.flat_padding(names, [tuple(t.shape) for t in tensors]).pad(tensors)
+            # zero-padded widths (utils/padding.py): the engine reads padded projection rows (scattered here with a torch
+            # op, so autograd gathers their gradient back) and returns the real entries of its padded parameter gradients
             index, width = eng.time_projection_index()
             rows = torch.zeros(rows.shape[0], width, dtype=rows.dtype, device=rows.device).index_copy(1, index, rows)
         return _UnetFunction.apply(eng, layout, x.contiguous().float(), rows, *tensors)

@@ -145,28 +145,32 @@ def pad_unet_state(state: Mapping[str, torch.Tensor], transition_dim: int, dim: 
 
 
 class FlatPadding:
-    """Many tensors padded with ONE scatter: the real tensors are flattened side by side, one ``index_copy`` drops them
-    into a zero vector that holds the padded tensors side by side, ``split_with_sizes`` hands out the views.  Every step
-    is a torch op, so autograd maps the gradients of the padded tensors back onto the real ones (an ``index_select``) —
-    this is how a net of zero-padded widths trains: the engine sees padded parameters, the optimiser the real ones."""
+    """Many tensors padded — or un-padded — with ONE scatter / gather over flat vectors: the real tensors flattened side
+    by side on one side, the padded tensors side by side (at ``offsets``, default: packed) on the other, ``index`` the
+    position of every real entry in the padded vector (gaps between tensors stay zero).  This is how a net of zero-padded widths trains: the engine
+    writes padded gradients into one flat buffer, ``gather`` hands autograd real-shaped views of one ``index_select`` of
+    it, and after an optimiser step ``pad_flat`` rebuilds the padded parameter copies on the device."""
 
-    def __init__(self, keys: Sequence[str], shapes: Sequence[Sequence[int]], plan: Mapping[str, list]):
+    def __init__(self, keys: Sequence[str], shapes: Sequence[Sequence[int]], plan: Mapping[str, list],
+                 offsets: Sequence[int] = None, total: int = None):
         self.keys = list(keys)
+        self.shapes = [tuple(int(d) for d in s) for s in shapes]
         self.padded_shapes: List[Tuple[int, ...]] = []
+        self.offsets: List[int] = []
         index, off = [], 0
-        for key, shape in zip(self.keys, shapes):
+        for i, (key, shape) in enumerate(zip(self.keys, self.shapes)):
             ps = list(shape)
             for axis, _, size in plan[key]:
                 ps[axis] = size
-            n = 1
-            for d in ps:
-                n *= d
-            where = unpad_tensor(torch.arange(n).view(ps), plan[key]).reshape(-1)
-            index.append(where + off)
+            n = int(torch.Size(ps).numel())
+            off = int(offsets[i]) if offsets is not None else (off + 3) // 4 * 4        # (packed: 16-byte aligned tensors)
+            index.append(unpad_tensor(torch.arange(n).view(ps), plan[key]).reshape(-1) + off)
             self.padded_shapes.append(tuple(ps))
+            self.offsets.append(off)
             off += n
         self.sizes = [int(torch.Size(s).numel()) for s in self.padded_shapes]
-        self.total = off
+        self.real_sizes = [int(torch.Size(s).numel()) for s in self.shapes]
+        self.total = int(total) if total is not None else off
         self.index = torch.cat(index) if index else torch.zeros(0, dtype=torch.long)
         self._on: Dict[str, torch.Tensor] = {}
 
@@ -176,8 +180,17 @@ class FlatPadding:
             self._on[key] = self.index.to(device)
         return self._on[key]
 
-    def pad(self, tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        """The padded tensors (views of one new vector), in the order of ``keys``; differentiable."""
+    def pad_flat(self, tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+        """The padded tensors side by side in one new vector (tensor k at ``offsets[k]``); differentiable."""
         flat = torch.cat([t.reshape(-1) for t in tensors]).float()
-        wide = torch.zeros(self.total, dtype=torch.float32, device=flat.device).index_copy(0, self.index_on(flat.device), flat)
-        return [v.view(s) for v, s in zip(wide.split_with_sizes(self.sizes), self.padded_shapes)]
+        return torch.zeros(self.total, dtype=torch.float32, device=flat.device).index_copy(0, self.index_on(flat.device), flat)
+
+    def pad(self, tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """The padded tensors as views of ``pad_flat``, in the order of ``keys``."""
+        wide = self.pad_flat(tensors)
+        return [wide[o:o + n].view(s) for o, n, s in zip(self.offsets, self.sizes, self.padded_shapes)]
+
+    def gather(self, wide: torch.Tensor) -> List[torch.Tensor]:
+        """Real-shaped views of ONE gather of the real entries out of the padded vector ``wide``."""
+        real = wide.index_select(0, self.index_on(wide.device))
+        return [v.view(s) for v, s in zip(real.split_with_sizes(self.real_sizes), self.shapes)]

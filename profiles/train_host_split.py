@@ -10,6 +10,8 @@ from dynamics_aware_diffusion_amd.utils import synth
 from dynamics_aware_diffusion_amd import _engine
 dev = torch.device("cuda:0")
 od, ad, dim, mults, T = synth.ARCHS["pointmaze"]
+for a in sys.argv[1:]:
+    if a.startswith("--dim="): dim = int(a[6:])
 td = od + ad
 unet = TemporalUnet(td, dim=dim, dim_mults=mults)
 unet.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_unet_state(td, dim, mults, seed=0).items()})
@@ -26,6 +28,7 @@ for _ in range(3):
     diff.loss(x0).backward()
 eng = diff.model._engine
 wrap(eng, "train_forward"); wrap(eng, "train_backward"); wrap(diff.model, "_time_projections"); wrap(diff, "q_sample")
+wrap(diff.model, "_forward_autograd"); wrap(diff.model, "engine"); wrap(eng, "grad_layout")
 lib = eng.lib
 N = 20
 torch.cuda.synchronize()
@@ -37,5 +40,5 @@ for _ in range(N):
 host = time.perf_counter() - t0
 torch.cuda.synchronize()
 total = time.perf_counter() - t0
-print(f"host loop {host / N * 1e3:.2f} ms/step (loss() {tl / N * 1e3:.2f}, backward() {tb / N * 1e3:.2f}); with final sync {total / N * 1e3:.2f} ms/step")
+print(f"dim {dim}: host loop {host / N * 1e3:.2f} ms/step (loss() {tl / N * 1e3:.2f}, backward() {tb / N * 1e3:.2f}); with final sync {total / N * 1e3:.2f} ms/step")
 for k, v in acc.items(): print(f"  {k}: {v / N * 1e3:.3f} ms/step (host)")

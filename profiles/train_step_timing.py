@@ -22,15 +22,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--arch", default="pointmaze", choices=sorted(synth.ARCHS))
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--repeats", type=int, default=5)
+ap.add_argument("--dim", type=int, default=0, help="override the architecture's dim (48 / 96: zero-padded GroupNorm groups)")
+ap.add_argument("--horizon", type=int, default=32, help="24 / 48 / 100: zero-padded rows")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 od, ad, dim, mults, T = synth.ARCHS[args.arch]
+dim = args.dim or dim
+H = args.horizon
 td = od + ad
 unet = TemporalUnet(td, dim=dim, dim_mults=mults)
 unet.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_unet_state(td, dim, mults, seed=0).items()})
-diff = GaussianDiffusion(unet, 32, od, ad, n_timesteps=T).to(dev)
-x0 = torch.from_numpy(synth.normal_like(3, "train.x0", (args.batch, 32, td))).to(dev).clamp(-1, 1)
-f = synth.unet_flops_per_sample(td, dim, mults, 32) * args.batch
+diff = GaussianDiffusion(unet, H, od, ad, n_timesteps=T).to(dev)
+x0 = torch.from_numpy(synth.normal_like(3, "train.x0", (args.batch, H, td))).to(dev).clamp(-1, 1)
+f = synth.unet_flops_per_sample(td, dim, mults, H) * args.batch      # (the REAL net's FLOPs: padding is overhead)
 fwd, bwd = [], []
 for rep in range(args.repeats + 1):
     for p in diff.parameters():
@@ -73,7 +77,7 @@ for _ in range(N):
 torch.cuda.synchronize()
 steady_opt = (time.perf_counter() - t0) / N
 fm, bm = min(fwd) * 1e3, min(bwd) * 1e3
-print(f"{args.arch} B={args.batch}: training forward {fm:.2f} ms ({f / fm / 1e9:.1f} TFLOP/s), backward {bm:.2f} ms "
+print(f"{args.arch} dim={dim} H={H} B={args.batch}: training forward {fm:.2f} ms ({f / fm / 1e9:.1f} TFLOP/s), backward {bm:.2f} ms "
       f"({2 * f / bm / 1e9:.1f} TFLOP/s algorithmic), {N} steps back to back {steady * 1e3:.2f} ms per step "
       f"({3 * f / steady / 1e12:.1f} TFLOP/s, {args.batch / steady:.0f} samples/s), with SGD step + weight refresh "
       f"{steady_opt * 1e3:.2f} ms per step ({args.batch / steady_opt:.0f} samples/s), loss {float(loss):.5f}", flush=True)

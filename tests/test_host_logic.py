@@ -116,6 +116,15 @@ def test_zero_padded_groups_keep_every_real_weight():
     for leaf, k in zip(leaves, keys):
         want = padding.unpad_tensor(torch.arange(padded[k].numel(), dtype=torch.float32).view(padded[k].shape), plan[k])
         assert torch.equal(leaf.grad, want), k
+    # ... and back: one gather of the real entries out of a flat padded vector laid out at given offsets (the engine's
+    # gradient buffer), tensors 16-byte aligned
+    offs, at = [], 8
+    for n in flat.sizes:
+        offs.append(at)
+        at += (n + 3) // 4 * 4 + 4
+    spaced = padding.FlatPadding(keys, [tuple(state[k].shape) for k in keys], plan, offs, at)
+    back = spaced.gather(spaced.pad_flat([state[k] for k in keys]))
+    assert all(torch.equal(b, state[k]) for b, k in zip(back, keys)) and all(o % 4 == 0 for o in flat.offsets)
     # the library's own expectations for the padded widths
     lib = _engine.load_library()
     cfg = _engine.DadCfg()
