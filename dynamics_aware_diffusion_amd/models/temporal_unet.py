@@ -96,6 +96,7 @@ class TemporalUnet(nn.Module):
         # False keeps every batch on the batch-256 kernels with grid-level split-K.
         self.small_batch_kernels = type(self).default_small_batch_kernels
         # engine state (not part of state_dict)
+        self._named: Optional[Dict[str, nn.Parameter]] = None
         self._engine: Optional[HipEngine] = None
         self._engine_sig = None
         self._engine_params = None
@@ -104,6 +105,25 @@ class TemporalUnet(nn.Module):
                                 "clip_denoised": True}
 
     # ------------------------------------------------------------------ engine plumbing
+    def _params(self) -> Dict[str, nn.Parameter]:
+        """name -> Parameter, walked once: the module tree is fixed after __init__ (``.to()`` / ``load_state_dict``
+        keep the Parameter objects), and every call of the model needs the list — 0.27 ms per walk for 160 tensors."""
+        if self._named is None:
+            self._named = dict(self.named_parameters())
+        return self._named
+
+    def __getstate__(self):
+        """``copy.deepcopy(model)`` / pickling (the reference's trainer keeps its EMA weights in a deep copy,
+        utils/training.py:77): the copy gets the parameters and options, not the engine — a ``dad_model`` handle
+        belongs to one object; the copy builds its own on its first call."""
+        state = dict(self.__dict__)
+        state.update(_engine=None, _engine_sig=None, _engine_params=None, _named=None)
+        return state
+
+    def _apply(self, fn, *args, **kwargs):
+        self._named = None                 # (a conversion may replace Parameter objects)
+        return super()._apply(fn, *args, **kwargs)
+
     def bind_diffusion(self, schedule: Dict[str, torch.Tensor], n_timesteps: int,
                        predict_epsilon: bool, clip_denoised: bool) -> None:
         """Called by ``GaussianDiffusion``: hands over the schedule scalars the fused
@@ -115,7 +135,7 @@ class TemporalUnet(nn.Module):
 
     def _signature(self, horizon: int, device: torch.device):
         """(what the engine's structure depends on, the parameters' identities and versions)"""
-        params = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        params = tuple((p.data_ptr(), p._version) for p in self._params().values())
         opts = tuple(sorted(self._diffusion_opts.items()))
         sched = None
         if self._schedule is not None:
@@ -134,10 +154,10 @@ class TemporalUnet(nn.Module):
         if self._engine is not None and sig == self._engine_sig and (self._engine.training or not training):
             if params == self._engine_params:
                 return self._engine
-            if self.precision == "fp32" and all(p.device == device for p in self.parameters()):
+            if self.precision == "fp32" and all(p.device == device for p in self._params().values()):
                 # only parameter VALUES changed (an optimiser step): the packed copies are re-derived on the
                 # device, no engine rebuild and no host round trip
-                self._engine.refresh(dict(self.named_parameters()))
+                self._engine.refresh(self._params())
                 self._engine_params = params
                 return self._engine
         opts = self._diffusion_opts
@@ -154,7 +174,7 @@ class TemporalUnet(nn.Module):
             sched = {k: zero for k in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
                                        "posterior_mean_coef1", "posterior_mean_coef2",
                                        "posterior_log_variance_clipped")}
-        eng.load(dict(self.named_parameters()), sched)
+        eng.load(self._params(), sched)
         eng.debug_set_option("cc", int(bool(self.small_batch_kernels)))
         self._engine, self._engine_sig, self._engine_params = eng, sig, params
         return eng
@@ -188,7 +208,7 @@ class TemporalUnet(nn.Module):
         """(B, sum C_out) = every block's Linear(Mish(time_mlp(SinusoidalPosEmb(t)))) side by side, with
         torch ops (temporal_unet.py:19-32,97-100,155-160): autograd differentiates these."""
         F = torch.nn.functional
-        p = dict(self.named_parameters())
+        p = self._params()
         half = self.dim // 2
         scale = math.log(10000) / (half - 1)
         freqs = torch.exp(torch.arange(half, device=time.device) * -scale)
@@ -207,7 +227,7 @@ class TemporalUnet(nn.Module):
     def _forward_autograd(self, x: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
         eng = self.engine(int(x.shape[1]), x.device, training=True)
         layout, _ = eng.grad_layout()
-        params = dict(self.named_parameters())
+        params = self._params()
         rows = self._time_projections(time.reshape(-1).to(x.device))
         tensors = [params[k] for k, _, _ in layout]
         if eng.widths_padded:
@@ -218,7 +238,7 @@ class TemporalUnet(nn.Module):
         return _UnetFunction.apply(eng, layout, x.contiguous().float(), rows, *tensors)
 
     def forward(self, x: torch.Tensor, time: Union[int, torch.Tensor]) -> torch.Tensor:
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._params().values())):
             if isinstance(time, int):
                 time = torch.full((x.shape[0],), time, device=x.device, dtype=torch.long)
             return self._forward_autograd(x, time)        # (any t: the sinusoid is evaluated, not looked up)

@@ -959,3 +959,25 @@ def test_small_batch_projected_loop_graph_equals_eager(dev):
     finally:
         diff.use_graph = False
         diff.sampler_rng = "torch"
+
+
+@pytest.mark.gpu
+def test_ema_copy_runs_its_own_engine(dev):
+    """``copy.deepcopy(diffusion)`` after the original has run (the reference's EMA model, utils/training.py:77-84): the
+    copy builds its own engine, gives the original's output, follows its own EMA update — and the original is unchanged."""
+    import copy
+    diff = build("tiny", 20, "cosine", dev)
+    x = torch.from_numpy(cases.forward_input("ema", "tiny", 3)).to(dev)
+    with torch.no_grad():
+        first = diff.model(x, 4).clone()
+        ema = copy.deepcopy(diff)
+        assert ema.model._engine is None
+        assert torch.equal(ema.model(x, 4), first) and ema.model._engine is not diff.model._engine
+        w = {k: v.clone() for k, v in net_weights_torch("tiny").items()}
+        for k, p in ema.model.named_parameters():           # an in-place update, as EMA.update_model_average makes
+            p.mul_(1.1)
+            w[k] = 1.1 * w[k]
+        got = ema.model(x, 4)
+        want = orc.unet_forward(w, x.cpu(), torch.full((3,), 4, dtype=torch.long))
+        assert max_abs(got.cpu().numpy(), want.numpy()) <= 2e-5
+        assert torch.equal(diff.model(x, 4), first)

@@ -676,3 +676,31 @@ def test_qr_projector_equals_the_pinv_projector():
     b = ProjectionMatrixBuilder(A, B, 7, 3)
     P = b.projection_matrix_on_device(16, "cpu")
     assert float((P - b.get_projection_matrix(16)).abs().max()) <= 1e-6 and b.verify_projection(P)
+
+
+def test_deepcopy_and_pickle_leave_the_engine_behind():
+    """The reference's trainer keeps EMA weights in ``copy.deepcopy(model)`` (utils/training.py:77): a copy of the
+    model gets parameters and options but no ``dad_model`` handle (ctypes pointers cannot be copied; the copy builds
+    its own engine on its first call), and the cached parameter walk follows the copy's own Parameters."""
+    import copy
+    import ctypes
+    import pickle
+    from dynamics_aware_diffusion_amd import GaussianDiffusion, TemporalUnet
+    unet = TemporalUnet(6, dim=32, dim_mults=(1, 2))
+    diff = GaussianDiffusion(unet, 8, 4, 2, n_timesteps=10)
+    unet._engine = ctypes.c_void_p(5)          # stands for a built engine: not copyable
+    unet.precision = "f16x3"
+    assert len(unet._params()) == len(list(unet.parameters()))
+    twin = copy.deepcopy(diff)
+    assert twin.model._engine is None and twin.model._engine_sig is None and twin.model.precision == "f16x3"
+    mine, theirs = dict(unet.named_parameters()), twin.model._params()
+    assert set(mine) == set(theirs)
+    assert all(torch.equal(mine[k], theirs[k]) and mine[k] is not theirs[k] for k in mine)
+    assert all(theirs[k] is p for k, p in twin.model.named_parameters())
+    with torch.no_grad():                       # an EMA update of the copy does not touch the original
+        for k in theirs:
+            theirs[k].mul_(0.5)
+    assert all(torch.equal(mine[k] * 0.5, theirs[k]) for k in mine)
+    unet._engine = None
+    back = pickle.loads(pickle.dumps(unet))
+    assert torch.equal(back.state_dict()["final_conv.1.weight"], unet.state_dict()["final_conv.1.weight"])
