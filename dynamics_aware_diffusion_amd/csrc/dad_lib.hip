@@ -1567,6 +1567,17 @@ int dad_unet_backward(dad_model* m, const float* x, const float* d_out, float* d
             if (f.res == -2) {                             // identity residual of the trajectory itself (td == C)
                 if ((rc = accumulate(dxpad, gout, out_floats, dx_written)) != DAD_OK) return rc;
                 dx_written = true;
+            } else if (f.cat0 >= 0) {                      // identity residual over [cat0 | cat1]: each side takes its columns
+                const long rows = (long)B * out_rows;
+                const int ids[2] = {f.cat0, f.cat1}, cs[2] = {f.cat_c0, f.cat_c1};
+                for (int k = 0, off = 0; k < 2; off += cs[k], ++k) {
+                    const int r = resolve(ids[k]);
+                    const long n4 = rows * (cs[k] / 4);
+                    hipLaunchKernelGGL(dad::take_cols_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                                       grd(ids[k]), gout, rows, cs[k], f.cout, off, (int)written[r]);
+                    written[r] = 1;
+                }
+                HIP_TRY(hipGetLastError());
             } else if (f.res >= 0) {
                 const int q = owner[f.res];
                 const bool conv_out = q >= 0 && convs[q].kind == CONV_1X1 && convs[q].norm.empty();

@@ -532,8 +532,6 @@ inline int build_backward_plan(HostModel* m) {
 // Why a model cannot be trained on this engine, or nullptr.
 inline const char* training_refusal(const HostModel& m) {
     if (m.precision != DAD_PREC_FP32) return "the backward pass exists for the fp32 arithmetic only";
-    for (const ConvOp& op : m.tplan.convs)
-        if (op.cat0 >= 0) return "identity residual over a channel concat (shrinking dim_mults) has no backward kernel";
     return nullptr;
 }
 

@@ -442,6 +442,20 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(float* out, const float*
     }
 }
 
+// dst[r][0..c) (+)= src[r][off .. off + c)   (src rows of ld floats; c, off, ld multiples of 4): one side of the gradient
+// of an identity residual over a channel concat — d [x | skip] = [d out[:, :c0] | d out[:, c0:]]
+__global__ void take_cols_kernel(float* dst, const float* src, long rows, int c, int ld, int off, int have) {
+    const int q = c >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * q) return;
+    const long r = i / q;
+    const int j = (int)(i - r * q) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src + r * ld + off + j);
+    float4* d = reinterpret_cast<float4*>(dst + r * c + j);
+    if (have) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    *d = v;
+}
+
 // y[i] += x[i]   (n4 float4s)
 __global__ void add_inplace_kernel(float* y, const float* x, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

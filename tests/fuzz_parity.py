@@ -16,12 +16,15 @@ shows how many launches of the case took them and how many the streamed-weight f
 `knobs` (round 3): kernel_size 3 / 5 / 7, level widths that need zero-padded GroupNorm groups (dim 8 / 24 / 40 /
 48 / 56 / 96), horizon up to 128; every third case also runs loss.backward() through the engine against the
 oracle's autograd (2e-5 x max|g| per tensor) where the net can be trained.
-`grads`: trainable nets only (non-shrinking mults; since padded widths train, every dim of `knobs`), gradients in every case.
+`grads`: fp32 only, gradients in every case (every dim and mults of `knobs`: padded widths and shrinking mults train).
 Round 3: seeds 61 / 62 / 63 `knobs` (150 cases ran: 116 on padded widths, 78 with kernel_size 3 / 7; 4 refusals — an
 identity residual over a concat with padded groups), seeds 71 / 72 `grads` (72 nets incl. widths up to 2048, horizons up to 128, kernel_size 3 / 7: worst gradient error
 5.5e-6 x max|g|), seeds 81 / 82 `knobs` and 91 `grads` with horizons 12 / 24 / 40 / 48 / 96 / 100 (zero-padded rows,
 gradients included): 0 failures.  Seeds 111 / 112 `grads` once padded WIDTHS train (130 cases, 93 of them on dims 8 / 24 / 40 /
-48 / 56 / 96 and mults incl. 3): worst gradient error 1.1e-5 x max|g|, 0 failures."""
+48 / 56 / 96 and mults incl. 3): worst gradient error 1.1e-5 x max|g|, 0 failures.  Final library of the round: seeds 121 `small`
+(32), 122 `wide`, 123 default (28), 124 `knobs` (42), 131 `grads` (53 nets, 11 of them with shrinking mults — identity residual
+over a concat — trained): 0 failures; one dim-8 net (one-channel groups over 6 positions) passes by the fp64 criterion
+(HIP 3.3e-6 from the float64 forward, the fp32 oracle 6.2e-6)."""
 import sys, random
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,7 +44,6 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     dim = rng.choice([32, 64, 128, 256] + ([8, 24, 40, 48, 56, 96] * 2 if knobs else []))
     nlev = rng.choice([1, 2, 3, 4])
     mults = tuple([1] + [rng.choice([1, 2, 4, 8] + ([3] if knobs else [])) for _ in range(nlev - 1)])
-    if grads: mults = tuple(sorted(mults))
     H = rng.choice([8, 16, 32, 64] + ([128, 12, 24, 40, 48, 96, 100] if knobs else []))
     ks = rng.choice([3, 5, 5, 7]) if knobs else 5
     if ((H >> (nlev - 1) < 4 or H & (H - 1)) and not knobs) or H % (1 << (nlev - 1)) or max(mults) * dim > 2048:
@@ -64,6 +66,13 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
             want = orc.unet_forward(w, x, torch.full((B,), t, dtype=torch.long))
             got = diff.model(x.to(dev), t); torch.cuda.synchronize()
         err = float((got.cpu() - want).abs().max())
+        note = ""
+        if err > 5e-6:
+            # ill-conditioned nets (GroupNorm groups of one channel over a few positions, dim 8): the fp64 criterion of
+            # the parity tests — no farther from the float64 forward than twice the fp32 oracle is
+            truth = orc.unet_forward(orc.cast_weights(w, torch.float64), x.double(), torch.full((B,), t, dtype=torch.long))
+            e_hip = float((got.cpu().double() - truth).abs().max()); e_ref = float((want.double() - truth).abs().max())
+            if e_hip <= 2 * e_ref + 5e-7: err, note = 0.0, f" [fwd by the fp64 criterion: hip {e_hip:.1e}, oracle {e_ref:.1e}]"
         # and a short conditioned sampling loop with injected noise (<= 2e-5, the loop tolerance)
         T = rng.randint(3, 12)
         Bl = min(B, 8)
@@ -88,7 +97,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
         gtxt = ""
         gerr = 0.0
         shrinking = any(b < a for a, b in zip(mults, mults[1:]))
-        if knobs and (grads or it % 3 == 0) and prec == "fp32" and not shrinking and td != dim:
+        if knobs and (grads or it % 3 == 0) and prec == "fp32" and td != dim:
             Bg = min(B, 6)
             x0 = torch.from_numpy(np.clip(synth.normal_like(400 + it, "fuzz.x0", (Bg, H, td)) * 0.5, -1, 1).astype(np.float32))
             tt = torch.from_numpy(np.array([(3 * i + 1) % 20 for i in range(Bg)], dtype=np.int64))
@@ -103,10 +112,18 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
             gscale = grad_scales(og)          # (max|g| per tensor; a conv bias in front of a one-channel group is exactly zero)
             for k_, p_ in diff.model.named_parameters():
                 gerr = max(gerr, float((p_.grad.cpu() - og[k_]).abs().max()) / gscale[k_])
+            if gerr > 2e-5:                  # the same criterion per gradient tensor
+                s64 = {k_: v_.double() for k_, v_ in orc.schedule_buffers("cosine", 20).items()}
+                _, t64, tdx = orc.training_gradients(orc.cast_weights(w, torch.float64), s64, x0.double(), tt, nz.double())
+                sc = grad_scales(t64)
+                ok = float((x_t.grad.cpu().double() - tdx).abs().max()) <= 2 * float((odx.double() - tdx).abs().max()) + 2e-6 * float(tdx.abs().max())
+                for k_, p_ in diff.model.named_parameters():
+                    ok = ok and float((p_.grad.cpu().double() - t64[k_]).abs().max()) <= 2 * float((og[k_].double() - t64[k_]).abs().max()) + 2e-6 * sc[k_]
+                if ok: note += f" [grads by the fp64 criterion, vs oracle {gerr:.1e}]"; gerr = 0.0
             gtxt = f" grads {gerr:.2e}"
         flag = "" if err <= 5e-6 and errl <= 2e-5 and gerr <= 2e-5 else "   <<<<<< FAIL"
         if flag: bad += 1
-        print(f"{it:3d} dim={dim} mults={mults} H={H} k={ks} td={td} B={B} {prec} t={t} padded={eng.padded} cc(launches, wide)={plan}: fwd {err:.2e} loop(T={T}) {errl:.2e}{gtxt}{flag}", flush=True)
+        print(f"{it:3d} dim={dim} mults={mults} H={H} k={ks} td={td} B={B} {prec} t={t} padded={eng.padded} cc(launches, wide)={plan}: fwd {err:.2e} loop(T={T}) {errl:.2e}{gtxt}{note}{flag}", flush=True)
         del unet, diff
     except Exception as e:
         msg = str(e)[:110]
