@@ -109,8 +109,9 @@ int dad_model_set_precision(dad_model* m, int32_t precision);
  * language pads every GroupNorm group of such a level with zero channels up to the next power of two >= 4 (weights,
  * biases, gamma / beta of the padding are zero: the padded net computes the same function), gives the PADDED widths
  * in dad_cfg and states the real ones here; the GroupNorm statistics then count the real channels only.  Call
- * between dad_model_create and dad_model_finalize.  Such models run the batch kernels at every batch size and are
- * refused by dad_model_set_training. */
+ * between dad_model_create and dad_model_finalize.  Such models run the batch kernels at every batch size; they
+ * train as the padded net (dad_unet_backward fills padded gradient tensors: the entries of the padding are garbage
+ * the host language drops; the GroupNorm backward counts the real channels). */
 int dad_model_set_group_channels(dad_model* m, const int32_t* real_channels, int32_t n_levels);
 
 /* Horizons the reference accepts and the tiles do not: its U-Net takes any length every level can halve
