@@ -24,7 +24,13 @@ gradients included): 0 failures.  Seeds 111 / 112 `grads` once padded WIDTHS tra
 48 / 56 / 96 and mults incl. 3): worst gradient error 1.1e-5 x max|g|, 0 failures.  Final library of the round: seeds 121 `small`
 (32), 122 `wide`, 123 default (28), 124 `knobs` (42), 131 `grads` (53 nets, 11 of them with shrinking mults — identity residual
 over a concat — trained): 0 failures; one dim-8 net (one-channel groups over 6 positions) passes by the fp64 criterion
-(HIP 3.3e-6 from the float64 forward, the fp32 oracle 6.2e-6)."""
+(HIP 3.3e-6 from the float64 forward, the fp32 oracle 6.2e-6).  Seed 132 `grads` (57 nets): two flagged, both at horizon 8 with
+kernel_size 7 on padded nets whose deepest level keeps ONE or TWO real positions — GroupNorm over 2 .. 12 values, where fp32
+itself is short: dim 8 (1, 1, 3): the oracle's own fp32 gradients are 1e-3 x max|g| from its float64 gradients (the HIP
+gradients pass by the fp64 criterion, the 4-step loop is 3.5e-5 off); dim 24 (1, 1, 1, 4): oracle fp32 3.4e-5 from float64
+on ups.0.0 / mid_block1, HIP 1.7e-4 from the oracle on the same tensors (d x 1.5e-5) — about five times the oracle's
+error, recorded as OPEN (ill-conditioned statistics amplify the convs' different summation order; no tensor is wrong
+by more than 2e-4 and every better-conditioned net of the sweep is within 1.1e-5).  DAD_FUZZ_VERBOSE=1 prints the worst tensors."""
 import sys, random
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -112,6 +118,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
             gscale = grad_scales(og)          # (max|g| per tensor; a conv bias in front of a one-channel group is exactly zero)
             for k_, p_ in diff.model.named_parameters():
                 gerr = max(gerr, float((p_.grad.cpu() - og[k_]).abs().max()) / gscale[k_])
+            if gerr > 2e-5 and os.environ.get("DAD_FUZZ_VERBOSE"):
+                worst_ = sorted(((float((p_.grad.cpu() - og[k_]).abs().max()) / gscale[k_], k_) for k_, p_ in diff.model.named_parameters()), reverse=True)[:8]
+                print("      d x:", float((x_t.grad.cpu() - odx).abs().max()) / max(float(odx.abs().max()), 1e-12), "worst tensors:", worst_, flush=True)
             if gerr > 2e-5:                  # the same criterion per gradient tensor
                 s64 = {k_: v_.double() for k_, v_ in orc.schedule_buffers("cosine", 20).items()}
                 _, t64, tdx = orc.training_gradients(orc.cast_weights(w, torch.float64), s64, x0.double(), tt, nz.double())
